@@ -1,0 +1,144 @@
+/*
+ * rt_mi355x.h -- C ABI of the MI355X (gfx950) per-pixel ray caster.
+ *
+ * Drop-in boundary for the Phlipsje/Raytracing host (reference citations are file:line in
+ * that tree).  The reference has no FFI; its seam is the OpenGL call sequence in
+ * RayTracer.cs.  Each entry point below replaces one of those call sites, takes exactly the
+ * buffers the C# host already builds (PrimitiveStructsForBuffer.cs:8-74 layouts, the
+ * serialised R-tree of RTree.cs:111-178, the lights array of RayTracer.cs:993-1005 and the
+ * 14-float camera array of RayTracer.cs:947-954) and is what a P/Invoke stub would bind
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions: every call returns 0 on success and a negative rt_status on failure; no
+ * exception crosses the ABI; rt_last_error() returns the message of the last failure on that
+ * context.  One host thread per context (as the reference's single render thread,
+ * OpenTK.cs:152,186,240).  Host arrays are read during the call only (glBufferData
+ * semantics).  Pixel row 0 is the BOTTOM row (gl_FragCoord, raytracer_fs.glsl:302-303).
+ *
+ * Hit ids (the reference outputs none; defined from its own R-tree pointer convention,
+ * IScene.cs:27-35, raytracer_fs.glsl:191-195): sphere i -> i, triangle j -> S + j,
+ * plane k -> S + T + k, miss -> -1.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_MALFORMED_ACCEL = -2, /* accel array fails validation (the shader would read out of bounds) */
+    RT_ERR_NO_SCENE = -3,
+    RT_ERR_DEVICE = -4,          /* a HIP call failed; rt_last_error() has hipGetErrorString */
+    RT_ERR_OUT_OF_MEMORY = -5,
+    RT_ERR_TOO_LARGE = -6        /* index does not fit the packed node format (>= 2^24 slots) */
+} rt_status;
+
+/* Deterministic work counters of one frame, counted by the REFERENCE algorithm's rules (every
+ * candidate tested, no distance cull; raytracer_fs.glsl:163-297): identical to the oracle's. */
+typedef struct rt_stats {
+    uint64_t primary_rays;      /* W*H                                                        */
+    uint64_t secondary_rays;    /* executed mirror-loop iterations, raytracer_fs.glsl:334-381 */
+    uint64_t shadow_rays;       /* ObjectInWayOfLight calls, raytracer_fs.glsl:350, 410       */
+    uint64_t node_tests;        /* IntersectBoundingBox calls, raytracer_fs.glsl:172          */
+    uint64_t refs_read;         /* accStruct[pos+8+i] reads, raytracer_fs.glsl:184, 191       */
+    uint64_t sphere_tests;      /* IntersectSphere calls                                      */
+    uint64_t plane_tests;       /* IntersectPlane calls on planes[]                           */
+    uint64_t triangle_tests;    /* IntersectTriangle calls                                    */
+    uint64_t material_fetches;  /* accepted closer hits in FindClosestIntersection            */
+    uint64_t reserved[7];
+} rt_stats;
+
+/* Render flags */
+enum {
+    RT_RENDER_DEFAULT = 0,
+    RT_RENDER_REFERENCE_ORDER = 1 /* run the exhaustive kernel that follows the reference's
+                                     candidate rules literally (used for rt_stats; slower) */
+};
+
+/* Replaces GL.CreateProgram + shader load/compile/link, RayTracer.cs:49-62.
+ * device_id: HIP device ordinal (one context per GPU; multi-GPU hosts create one per rank). */
+int rt_create(int device_id, rt_ctx** out);
+void rt_destroy(rt_ctx* ctx);
+/* The reference only prints GL info logs (RayTracer.cs:53-56, 1054). */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Replaces RayTracer.SendPrimitivesToShader, RayTracer.cs:957-1046 (glBufferData x4 +
+ * glUniform x2).  spheres: SphereStruct[n] 48 B; planes: PlaneStruct[n] 64 B; triangles:
+ * TriangleStruct[n] 96 B; accel: IScene.AccelerationStructureData; lights: 6 floats per light
+ * (position xyz, intensity rgb), lights_len = 6*L.  The reference caps L at 50
+ * (RayTracer.cs:960); this library does not.  The 32-bit word at the IsPureSpecular offset is
+ * read as != 0.  Validates the accel array completely (bounds, forward child offsets, ids)
+ * and flattens it for the GPU; a malformed array is rejected with RT_ERR_MALFORMED_ACCEL. */
+int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
+                    const void* triangles, int n_triangles, const float* accel, int64_t accel_len,
+                    const float* lights, int lights_len);
+
+/* Replaces PrepareRenderOpenGL + RenderGL, RayTracer.cs:943-956 and 125-137 (glUniform of the
+ * camera + the full-screen draw).  camera: the 14 floats exactly as packed at
+ * RayTracer.cs:947-954 (position, bottom-left, bottom-right, top-left, width, height).
+ * max_bounces: the shader's maxBounces constant (raytracer_fs.glsl:7 fixes it at 10).
+ * Outputs are HOST arrays of W*H pixels, any may be NULL: rgb 3 floats (unclamped
+ * outputColor.rgb), rgba8 = round-half-even(clamp(c,0,1)*255) with A=255, primary_id /
+ * final_id = hit id of the first ray / of the finally shaded hit, stats (forces the
+ * reference-order kernel). */
+int rt_render(rt_ctx* ctx, const float camera[14], int max_bounces, float* rgb, uint8_t* rgba8,
+              int32_t* primary_id, int32_t* final_id, rt_stats* stats);
+
+/* Device-resident form of rt_render for hosts that keep the frame in HBM (no counterpart in
+ * the reference, whose frame stays in the GL framebuffer, RayTracer.cs:135).
+ * Renders the rows owned by `rank` when the image is cut into bands of `band_rows` rows dealt
+ * round-robin to `world` ranks (rank 0, world 1, any band_rows = whole frame).  Local row r
+ * is global row ((r / band_rows) * world + rank) * band_rows + r % band_rows; outputs are
+ * DEVICE pointers to compact arrays of rt_local_rows() * W pixels (NULL = not wanted).
+ * d_bounces: int32 bounce count per pixel.  d_stats: device pointer to one rt_stats that is
+ * ACCUMULATED into (caller zeroes it), only honoured with RT_RENDER_REFERENCE_ORDER.
+ * stream: a hipStream_t (NULL = default stream); the call is asynchronous on it. */
+int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int flags, int band_rows,
+                     int rank, int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id,
+                     int32_t* d_final_id, int32_t* d_bounces, rt_stats* d_stats, void* stream);
+
+/* Number of rows rank renders (see rt_render_device), and the padded per-rank row count that
+ * makes every rank's contribution equal-sized for a gather. */
+int rt_local_rows(int height, int band_rows, int rank, int world);
+int rt_padded_rows(int height, int band_rows, int world);
+
+/* After an all-gather/gather of `world` equal contributions of rt_padded_rows()*W pixels of
+ * elem_size bytes each (rank-major), restore scanline order into d_out (H*W pixels).
+ * elem_size must be 4 or 12.  No counterpart in the reference (single GPU). */
+int rt_unpermute_bands(rt_ctx* ctx, const void* d_gathered, void* d_out, int elem_size, int width,
+                       int height, int band_rows, int world, void* stream);
+
+/* Introspection for tests and the bench: sizes of the flattened structures on the device. */
+typedef struct rt_scene_info {
+    int64_t n_nodes;        /* flattened node records (32 B each)                  */
+    int64_t n_tri_slots;    /* triangle geometry slots in traversal order (48 B)   */
+    int64_t n_sphere_slots; /* sphere geometry slots in traversal order (16 B)     */
+    int64_t max_depth;      /* deepest node of the R-tree                          */
+    int64_t device_bytes;   /* bytes of HBM held by the scene                      */
+    int64_t lds_scene_bytes;/* bytes the LDS-resident variant would need (0 = n/a) */
+    int64_t reserved[2];
+} rt_scene_info;
+int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out);
+
+/* Per-function device evaluators of the four intersection routines, one case per element
+ * (raytracer_fs.glsl:134-161, 93-113, 114-120, 121-131).  Host arrays; used by the parity
+ * tests to pin the device arithmetic bit-for-bit against the oracle. */
+int rt_eval_box(rt_ctx* ctx, int n, const float* o3, const float* d3, const float* box6, int32_t* hit);
+int rt_eval_sphere(rt_ctx* ctx, int n, const float* o3, const float* d3, const float* c3r, float* out4);
+int rt_eval_plane(rt_ctx* ctx, int n, const float* o3, const float* d3, const float* p3, const float* n3,
+                  float* t);
+int rt_eval_triangle(rt_ctx* ctx, int n, const float* o3, const float* d3, const float* a3, const float* b3,
+                     const float* c3, const float* n3, float* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

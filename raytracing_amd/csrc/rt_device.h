@@ -1,0 +1,186 @@
+// rt_device.h -- device-side scene view and the per-ray routines (gfx950, wave64).
+//
+// The arithmetic of every routine follows raytracer_fs.glsl line by line in the canonical
+// binary32 rules of rt_math.h, so that hit ids and ray counts are bit-exact against the
+// oracle.  What is NOT taken from the shader is the organisation: the stackless fixed-order
+// traversal over the flattened tree (rt_flatten.h), streaming of leaf primitives with an
+// explicit tie-break rank instead of candidate lists, and the hot/cold split of geometry and
+// material.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_flatten.h"
+#include "rt_math.h"
+#include "../../include/rt_mi355x.h"
+
+#pragma clang fp contract(off)
+
+namespace rtd {
+using namespace rtm;
+
+struct DevScene {
+    const float4* nodes;        // 2 x float4 per node (rtf::FlatNode)
+    const float4* tri_geom;     // 3 x float4 per triangle slot: A.xyz B.x | B.yz C.xy | C.z N.xyz
+    const float4* sphere_geom;  // 1 x float4 per sphere slot: center.xyz radius
+    const float4* plane_geom;   // 2 x float4 per plane: position.xyz 0 | normal.xyz 0
+    const int32_t* tri_slot_id;
+    const int32_t* sphere_slot_id;
+    const unsigned char* spheres_aos;  // the uploaded SphereStruct / PlaneStruct / TriangleStruct arrays
+    const unsigned char* planes_aos;   // (cold: only the winning hit's material is read from them)
+    const unsigned char* tris_aos;
+    const float* lights;
+    int32_t n_nodes, n_planes, n_spheres, n_tris, lights_len;
+};
+
+struct Ray {
+    V3 o, d;
+};
+
+constexpr float RT_FLT_BIG = 3.402823466e+38f;  // raytracer_fs.glsl:315
+constexpr float RT_EPSILON = 0.001f;            // raytracer_fs.glsl:4
+
+// ---- raytracer_fs.glsl:93-113 ------------------------------------------------------------
+__device__ __forceinline__ float4 IntersectSphere(V3 o, V3 d, V3 center, float radius) {
+    V3 v = o - center;
+    float b = 2 * (d.x * v.x + d.y * v.y + d.z * v.z);
+    float c = v.x * v.x + v.y * v.y + v.z * v.z - radius * radius;
+    float disc = b * b - 4 * c;
+    if (disc < 0) return make_float4(-1, -1, -1, -1);
+    float rootd = sqrtf(disc);
+    float t1 = (-b + rootd) / 2;
+    float t2 = (-b - rootd) / 2;
+    if (t1 < 0) return make_float4(-1, -1, -1, -1);
+    float t = (t2 < 0) ? t1 : t2;
+    V3 n = normalize((o + t * d) - center);
+    return make_float4(n.x, n.y, n.z, t);
+}
+// distance only (shadow rays use .w alone, raytracer_fs.glsl:213)
+__device__ __forceinline__ float IntersectSphereT(V3 o, V3 d, V3 center, float radius) {
+    V3 v = o - center;
+    float b = 2 * (d.x * v.x + d.y * v.y + d.z * v.z);
+    float c = v.x * v.x + v.y * v.y + v.z * v.z - radius * radius;
+    float disc = b * b - 4 * c;
+    if (disc < 0) return -1;
+    float rootd = sqrtf(disc);
+    float t1 = (-b + rootd) / 2;
+    float t2 = (-b - rootd) / 2;
+    if (t1 < 0) return -1;
+    return (t2 < 0) ? t1 : t2;
+}
+// ---- raytracer_fs.glsl:114-120 -----------------------------------------------------------
+__device__ __forceinline__ float IntersectPlane(V3 o, V3 d, V3 center, V3 normal) {
+    float den = dot(d, normal);
+    if (den == 0) return -1;
+    return dot(center - o, normal) / den;
+}
+// ---- raytracer_fs.glsl:121-131 -----------------------------------------------------------
+__device__ __forceinline__ float IntersectTriangle(V3 o, V3 d, V3 A, V3 B, V3 C, V3 N) {
+    float t = IntersectPlane(o, d, A, N);
+    if (t <= 0) return -1;
+    V3 X = o + t * d;
+    bool outside = dot(cross(B - A, X - A), N) < 0 || dot(cross(C - B, X - B), N) < 0 ||
+                   dot(cross(A - C, X - C), N) < 0;
+    return outside ? -1.0f : t;
+}
+
+// ---- raytracer_fs.glsl:134-161 -----------------------------------------------------------
+// The shader recomputes 1/dir and the sign selects per node; they depend on the ray only, so
+// they are computed once per ray here (same values, same comparisons).
+struct BoxRay {
+    V3 o, inv;
+    bool sx, sy, sz;
+};
+__device__ __forceinline__ BoxRay make_box_ray(V3 o, V3 d) {
+    BoxRay r;
+    r.o = o;
+    r.inv = v3(1 / d.x, 1 / d.y, 1 / d.z);
+    r.sx = r.inv.x < 0, r.sy = r.inv.y < 0, r.sz = r.inv.z < 0;
+    return r;
+}
+__device__ __forceinline__ bool IntersectBoundingBox(const BoxRay& r, float4 lo, float4 hi) {
+    float txmin = ((r.sx ? hi.x : lo.x) - r.o.x) * r.inv.x;
+    float txmax = ((r.sx ? lo.x : hi.x) - r.o.x) * r.inv.x;
+    float tymin = ((r.sy ? hi.y : lo.y) - r.o.y) * r.inv.y;
+    float tymax = ((r.sy ? lo.y : hi.y) - r.o.y) * r.inv.y;
+    if ((txmin > tymax) || (tymin > txmax)) return false;
+    if (tymin > txmin) txmin = tymin;
+    if (tymax < txmax) txmax = tymax;
+    float tzmin = ((r.sz ? hi.z : lo.z) - r.o.z) * r.inv.z;
+    float tzmax = ((r.sz ? lo.z : hi.z) - r.o.z) * r.inv.z;
+    if ((txmin > tzmax) || (tzmin > txmax)) return false;
+    return true;
+}
+
+// ---- geometry fetch ----------------------------------------------------------------------
+struct TriG {
+    V3 A, B, C, N;
+};
+__device__ __forceinline__ TriG load_tri(const float4* g, int slot) {
+    float4 q0 = g[3 * slot], q1 = g[3 * slot + 1], q2 = g[3 * slot + 2];
+    TriG t;
+    t.A = v3(q0.x, q0.y, q0.z);
+    t.B = v3(q0.w, q1.x, q1.y);
+    t.C = v3(q1.z, q1.w, q2.x);
+    t.N = v3(q2.y, q2.z, q2.w);
+    return t;
+}
+
+// Hit being tracked during a closest-hit query.  kind is the reference's candidate class in
+// test order (raytracer_fs.glsl:250, 268, 283): 0 sphere, 1 plane, 2 triangle; 3 = none.
+struct Closest {
+    float t;
+    int kind;
+    int index;  // sphere slot, plane index or triangle slot
+    V3 n;       // sphere normal (computed at acceptance); planes/triangles fetch theirs later
+};
+__device__ __forceinline__ Closest fresh_closest() { return Closest{RT_FLT_BIG, 3, -1, v3(0, 0, 0)}; }
+
+// The shader tests all spheres, then all planes, then all triangles and accepts on strict
+// t < best; the winner is therefore the first candidate in (class, visit order) among those
+// of minimal t.  A streaming traversal meets classes interleaved, so equal t is resolved by
+// class rank; within a class the visit order is preserved and strict < keeps the first.
+__device__ __forceinline__ bool closer(float t, int kind, float minDistance, const Closest& h) {
+    return t > minDistance && (t < h.t || (t == h.t && kind < h.kind));
+}
+
+// Material + normal of the winning hit (cold data, one fetch per query that hit something).
+struct Surface {
+    V3 diffuse, specular, normal;
+    float specularity;
+    bool pure;
+    int id;  // S/T/P id convention of rt_mi355x.h
+};
+__device__ __forceinline__ Surface resolve_surface(const DevScene& S, const Closest& h) {
+    Surface s;
+    const unsigned char* rec;
+    int mat;  // byte offset of diffuse inside the record
+    if (h.kind == 0) {
+        int id = S.sphere_slot_id[h.index];
+        rec = S.spheres_aos + (size_t)id * 48;
+        mat = 16;
+        s.normal = h.n;
+        s.id = id;
+    } else if (h.kind == 1) {
+        rec = S.planes_aos + (size_t)h.index * 64;
+        mat = 32;
+        const float* nf = (const float*)(rec + 16);
+        s.normal = v3(nf[0], nf[1], nf[2]);
+        s.id = S.n_spheres + S.n_tris + h.index;
+    } else {
+        int id = S.tri_slot_id[h.index];
+        rec = S.tris_aos + (size_t)id * 96;
+        mat = 64;
+        const float* nf = (const float*)(rec + 48);
+        s.normal = v3(nf[0], nf[1], nf[2]);
+        s.id = S.n_spheres + id;
+    }
+    const float4 m0 = *(const float4*)(rec + mat);       // diffuse.rgb, isPureSpecular word
+    const float4 m1 = *(const float4*)(rec + mat + 16);  // specular.rgb, specularity
+    s.diffuse = v3(m0.x, m0.y, m0.z);
+    s.pure = __float_as_uint(m0.w) != 0u;
+    s.specular = v3(m1.x, m1.y, m1.z);
+    s.specularity = m1.w;
+    return s;
+}
+
+}  // namespace rtd

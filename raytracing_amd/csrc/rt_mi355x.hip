@@ -1,0 +1,358 @@
+// rt_mi355x.hip -- C ABI of include/rt_mi355x.h: context, scene upload (validate + flatten +
+// GPU re-layout), render launches, band un-permute, per-function evaluators.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.h"
+
+using namespace rtd;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    std::string error;
+    bool has_scene = false;
+    DevScene scene{};
+    rt_scene_info info{};
+    // scene buffers
+    DevBuf nodes, tri_geom, sphere_geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos,
+        tris_aos, lights;
+    // frame buffers of rt_render (grow only)
+    DevBuf fb_rgb, fb_rgba8, fb_pid, fb_fid, fb_stats;
+    // scratch of the evaluators
+    DevBuf ev[8];
+};
+
+namespace {
+
+int fail(rt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    return code;
+}
+int hip_fail(rt_ctx* ctx, hipError_t e, const char* what) {
+    return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(ctx, expr)                                     \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #expr); \
+    } while (0)
+
+int ensure(rt_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.bytes && b.p) return RT_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(ctx, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return RT_OK;
+}
+int upload(rt_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+    int rc = ensure(ctx, b, bytes);
+    if (rc != RT_OK) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+int camera_size(const float* cam, int* w, int* h) {
+    if (!cam) return RT_ERR_INVALID_ARGUMENT;
+    const float fw = cam[12], fh = cam[13];
+    if (!(fw >= 1.0f) || !(fh >= 1.0f) || !(fw <= 65536.0f) || !(fh <= 65536.0f)) return RT_ERR_INVALID_ARGUMENT;
+    if (fw != (float)(int)fw || fh != (float)(int)fh) return RT_ERR_INVALID_ARGUMENT;
+    *w = (int)fw;
+    *h = (int)fh;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_local_rows(int height, int band_rows, int rank, int world) {
+    if (height <= 0 || band_rows <= 0 || world <= 0 || rank < 0 || rank >= world) return 0;
+    const int n_bands = (height + band_rows - 1) / band_rows;
+    int rows = 0;
+    for (int b = rank; b < n_bands; b += world) rows += std::min(band_rows, height - b * band_rows);
+    return rows;
+}
+
+int rt_padded_rows(int height, int band_rows, int world) {
+    if (height <= 0 || band_rows <= 0 || world <= 0) return 0;
+    const int n_bands = (height + band_rows - 1) / band_rows;
+    return ((n_bands + world - 1) / world) * band_rows;
+}
+
+int rt_create(int device_id, rt_ctx** out) {
+    if (!out) return RT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device_id < 0 || device_id >= n) return RT_ERR_DEVICE;
+    rt_ctx* ctx = new rt_ctx();
+    ctx->device = device_id;
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) {
+        delete ctx;
+        return RT_ERR_DEVICE;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    DevBuf* all[] = {&ctx->nodes,      &ctx->tri_geom,   &ctx->sphere_geom, &ctx->plane_geom, &ctx->tri_slot_id,
+                     &ctx->sphere_slot_id, &ctx->spheres_aos, &ctx->planes_aos, &ctx->tris_aos, &ctx->lights,
+                     &ctx->fb_rgb,     &ctx->fb_rgba8,   &ctx->fb_pid,      &ctx->fb_fid,     &ctx->fb_stats};
+    for (DevBuf* b : all) release(*b);
+    for (DevBuf& b : ctx->ev) release(b);
+    delete ctx;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
+                    const void* triangles, int n_triangles, const float* accel, int64_t accel_len,
+                    const float* lights, int lights_len) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (n_spheres < 0 || n_planes < 0 || n_triangles < 0 || accel_len < 0 || lights_len < 0 || lights_len % 6 != 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "negative count or lights_len not a multiple of 6");
+    if ((n_spheres && !spheres) || (n_planes && !planes) || (n_triangles && !triangles) || (accel_len && !accel) ||
+        (lights_len && !lights))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->has_scene = false;
+
+    rtf::Flat flat;
+    std::string err;
+    int rc = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &flat, &err);
+    if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
+
+    if ((rc = upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48))) return rc;
+    if ((rc = upload(ctx, ctx->planes_aos, planes, (size_t)n_planes * 64))) return rc;
+    if ((rc = upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96))) return rc;
+    if ((rc = upload(ctx, ctx->lights, lights, (size_t)lights_len * 4))) return rc;
+    if ((rc = upload(ctx, ctx->nodes, flat.nodes.data(), flat.nodes.size() * sizeof(rtf::FlatNode)))) return rc;
+    if ((rc = upload(ctx, ctx->tri_slot_id, flat.tri_slot_id.data(), flat.tri_slot_id.size() * 4))) return rc;
+    if ((rc = upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), flat.sphere_slot_id.size() * 4)))
+        return rc;
+    const int n_ts = (int)flat.tri_slot_id.size(), n_ss = (int)flat.sphere_slot_id.size();
+    if ((rc = ensure(ctx, ctx->tri_geom, (size_t)n_ts * 48))) return rc;
+    if ((rc = ensure(ctx, ctx->sphere_geom, (size_t)n_ss * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->plane_geom, (size_t)n_planes * 32))) return rc;
+
+    // GPU re-layout: AoS upload -> traversal-order geometry slots
+    if (n_ts)
+        hipLaunchKernelGGL(k_gather_tris, dim3((n_ts + 255) / 256), dim3(256), 0, 0,
+                           (const unsigned char*)ctx->tris_aos.p, (const int32_t*)ctx->tri_slot_id.p,
+                           (float4*)ctx->tri_geom.p, n_ts);
+    if (n_ss)
+        hipLaunchKernelGGL(k_gather_spheres, dim3((n_ss + 255) / 256), dim3(256), 0, 0,
+                           (const unsigned char*)ctx->spheres_aos.p, (const int32_t*)ctx->sphere_slot_id.p,
+                           (float4*)ctx->sphere_geom.p, n_ss);
+    if (n_planes)
+        hipLaunchKernelGGL(k_gather_planes, dim3((n_planes + 255) / 256), dim3(256), 0, 0,
+                           (const unsigned char*)ctx->planes_aos.p, (float4*)ctx->plane_geom.p, n_planes);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+
+    DevScene& s = ctx->scene;
+    s.nodes = (const float4*)ctx->nodes.p;
+    s.tri_geom = (const float4*)ctx->tri_geom.p;
+    s.sphere_geom = (const float4*)ctx->sphere_geom.p;
+    s.plane_geom = (const float4*)ctx->plane_geom.p;
+    s.tri_slot_id = (const int32_t*)ctx->tri_slot_id.p;
+    s.sphere_slot_id = (const int32_t*)ctx->sphere_slot_id.p;
+    s.spheres_aos = (const unsigned char*)ctx->spheres_aos.p;
+    s.planes_aos = (const unsigned char*)ctx->planes_aos.p;
+    s.tris_aos = (const unsigned char*)ctx->tris_aos.p;
+    s.lights = (const float*)ctx->lights.p;
+    s.n_nodes = (int32_t)flat.nodes.size();
+    s.n_planes = n_planes;
+    s.n_spheres = n_spheres;
+    s.n_tris = n_triangles;
+    s.lights_len = lights_len;
+
+    rt_scene_info& inf = ctx->info;
+    std::memset(&inf, 0, sizeof inf);
+    inf.n_nodes = (int64_t)flat.nodes.size();
+    inf.n_tri_slots = n_ts;
+    inf.n_sphere_slots = n_ss;
+    inf.max_depth = flat.max_depth;
+    inf.device_bytes = (int64_t)(flat.nodes.size() * 32 + (size_t)n_ts * 52 + (size_t)n_ss * 20 +
+                                 (size_t)n_planes * 96 + (size_t)n_spheres * 48 + (size_t)n_triangles * 96 +
+                                 (size_t)lights_len * 4);
+    inf.lds_scene_bytes = (int64_t)(flat.nodes.size() * 32 + (size_t)n_ts * 48 + (size_t)n_ss * 16);
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out) {
+    if (!ctx || !out) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return RT_ERR_NO_SCENE;
+    *out = ctx->info;
+    return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int flags, int band_rows, int rank,
+                     int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id, int32_t* d_final_id,
+                     int32_t* d_bounces, rt_stats* d_stats, void* stream) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_upload_scene has not succeeded on this context");
+    int w, h;
+    if (camera_size(camera, &w, &h) != RT_OK)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "camera[12..13] must hold an integral width/height in 1..65536");
+    if (max_bounces < 0 || band_rows <= 0 || world <= 0 || rank < 0 || rank >= world)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad max_bounces / band_rows / rank / world");
+    if (((uintptr_t)d_rgba8 & 3) != 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "d_rgba8 must be 4-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    RenderArgs a;
+    a.scene = ctx->scene;
+    std::memcpy(a.cam, camera, sizeof a.cam);
+    a.max_bounces = max_bounces;
+    a.width = w, a.height = h;
+    a.local_rows = rt_local_rows(h, band_rows, rank, world);
+    a.band_rows = band_rows, a.rank = rank, a.world = world;
+    a.tiles_x = (w + TILE - 1) / TILE;
+    a.n_tiles = a.tiles_x * ((a.local_rows + TILE - 1) / TILE);
+    a.rgb = d_rgb;
+    a.rgba8 = (uint32_t*)d_rgba8;
+    a.primary_id = d_primary_id;
+    a.final_id = d_final_id;
+    a.bounces = d_bounces;
+    a.stats = (unsigned long long*)d_stats;
+    if (a.n_tiles == 0) return RT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (flags & RT_RENDER_REFERENCE_ORDER)
+        hipLaunchKernelGGL(k_render<true>, dim3(a.n_tiles), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_render<false>, dim3(a.n_tiles), dim3(256), 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* ctx, const float camera[14], int max_bounces, float* rgb, uint8_t* rgba8,
+              int32_t* primary_id, int32_t* final_id, rt_stats* stats) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    int w, h;
+    if (camera_size(camera, &w, &h) != RT_OK)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "camera[12..13] must hold an integral width/height in 1..65536");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)w * h;
+    int rc;
+    if (rgb && (rc = ensure(ctx, ctx->fb_rgb, px * 12))) return rc;
+    if (rgba8 && (rc = ensure(ctx, ctx->fb_rgba8, px * 4))) return rc;
+    if (primary_id && (rc = ensure(ctx, ctx->fb_pid, px * 4))) return rc;
+    if (final_id && (rc = ensure(ctx, ctx->fb_fid, px * 4))) return rc;
+    if (stats) {
+        if ((rc = ensure(ctx, ctx->fb_stats, sizeof(rt_stats)))) return rc;
+        HIP_TRY(ctx, hipMemset(ctx->fb_stats.p, 0, sizeof(rt_stats)));
+    }
+    rc = rt_render_device(ctx, camera, max_bounces, stats ? RT_RENDER_REFERENCE_ORDER : RT_RENDER_DEFAULT, h, 0, 1,
+                          rgb ? (float*)ctx->fb_rgb.p : nullptr, rgba8 ? (uint8_t*)ctx->fb_rgba8.p : nullptr,
+                          primary_id ? (int32_t*)ctx->fb_pid.p : nullptr,
+                          final_id ? (int32_t*)ctx->fb_fid.p : nullptr, nullptr,
+                          stats ? (rt_stats*)ctx->fb_stats.p : nullptr, nullptr);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (rgb) HIP_TRY(ctx, hipMemcpy(rgb, ctx->fb_rgb.p, px * 12, hipMemcpyDeviceToHost));
+    if (rgba8) HIP_TRY(ctx, hipMemcpy(rgba8, ctx->fb_rgba8.p, px * 4, hipMemcpyDeviceToHost));
+    if (primary_id) HIP_TRY(ctx, hipMemcpy(primary_id, ctx->fb_pid.p, px * 4, hipMemcpyDeviceToHost));
+    if (final_id) HIP_TRY(ctx, hipMemcpy(final_id, ctx->fb_fid.p, px * 4, hipMemcpyDeviceToHost));
+    if (stats) HIP_TRY(ctx, hipMemcpy(stats, ctx->fb_stats.p, sizeof(rt_stats), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_unpermute_bands(rt_ctx* ctx, const void* d_gathered, void* d_out, int elem_size, int width, int height,
+                       int band_rows, int world, void* stream) {
+    if (!ctx || !d_gathered || !d_out) return RT_ERR_INVALID_ARGUMENT;
+    if ((elem_size != 4 && elem_size != 12) || width <= 0 || height <= 0 || band_rows <= 0 || world <= 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "elem_size must be 4 or 12; sizes must be positive");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int dwords = elem_size / 4;
+    const size_t total = (size_t)width * height * dwords;
+    const int padded = rt_padded_rows(height, band_rows, world);
+    hipLaunchKernelGGL(k_unpermute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t*)d_gathered, (uint32_t*)d_out, dwords, width, height, band_rows, world,
+                       padded);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// ---- per-function evaluators -------------------------------------------------------------
+static int eval_common(rt_ctx* ctx, int n, const void* const* in, const int* in_floats, int n_in, void* out,
+                       int out_bytes_per, int which) {
+    if (!ctx || n < 0) return RT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return RT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    for (int k = 0; k < n_in; k++) {
+        if (!in[k]) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null input");
+        if ((rc = upload(ctx, ctx->ev[k], in[k], (size_t)n * in_floats[k] * 4))) return rc;
+    }
+    if ((rc = ensure(ctx, ctx->ev[7], (size_t)n * out_bytes_per))) return rc;
+    const dim3 g((n + 255) / 256), b(256);
+    auto F = [&](int k) { return (const float*)ctx->ev[k].p; };
+    switch (which) {
+        case 0: hipLaunchKernelGGL(k_eval_box, g, b, 0, 0, n, F(0), F(1), F(2), (int32_t*)ctx->ev[7].p); break;
+        case 1: hipLaunchKernelGGL(k_eval_sphere, g, b, 0, 0, n, F(0), F(1), F(2), (float4*)ctx->ev[7].p); break;
+        case 2: hipLaunchKernelGGL(k_eval_plane, g, b, 0, 0, n, F(0), F(1), F(2), F(3), (float*)ctx->ev[7].p); break;
+        case 3:
+            hipLaunchKernelGGL(k_eval_triangle, g, b, 0, 0, n, F(0), F(1), F(2), F(3), F(4), F(5),
+                               (float*)ctx->ev[7].p);
+            break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(out, ctx->ev[7].p, (size_t)n * out_bytes_per, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_eval_box(rt_ctx* ctx, int n, const float* o3, const float* d3, const float* box6, int32_t* hit) {
+    const void* in[] = {o3, d3, box6};
+    const int fl[] = {3, 3, 6};
+    return eval_common(ctx, n, in, fl, 3, hit, 4, 0);
+}
+int rt_eval_sphere(rt_ctx* ctx, int n, const float* o3, const float* d3, const float* c3r, float* out4) {
+    const void* in[] = {o3, d3, c3r};
+    const int fl[] = {3, 3, 4};
+    return eval_common(ctx, n, in, fl, 3, out4, 16, 1);
+}
+int rt_eval_plane(rt_ctx* ctx, int n, const float* o3, const float* d3, const float* p3, const float* n3, float* t) {
+    const void* in[] = {o3, d3, p3, n3};
+    const int fl[] = {3, 3, 3, 3};
+    return eval_common(ctx, n, in, fl, 4, t, 4, 2);
+}
+int rt_eval_triangle(rt_ctx* ctx, int n, const float* o3, const float* d3, const float* a3, const float* b3,
+                     const float* c3, const float* n3, float* t) {
+    const void* in[] = {o3, d3, a3, b3, c3, n3};
+    const int fl[] = {3, 3, 3, 3, 3, 3};
+    return eval_common(ctx, n, in, fl, 6, t, 4, 3);
+}
+
+}  // extern "C"
