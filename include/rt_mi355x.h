@@ -128,6 +128,14 @@ typedef struct rt_scene_info {
 } rt_scene_info;
 int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out);
 
+/* Host-only validation + flatten dry run of an accel array: the same checks rt_upload_scene
+ * applies, without a context or a GPU.  info (may be NULL) receives the flattened sizes; err
+ * (may be NULL) receives the message.  Returns RT_OK, RT_ERR_MALFORMED_ACCEL or RT_ERR_TOO_LARGE.
+ * The reference never validates: a bad array makes the shader read out of bounds
+ * (raytracer_fs.glsl:65-68, 173-195). */
+int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_triangles, rt_scene_info* info,
+                   char* err, size_t err_cap);
+
 /* Per-function device evaluators of the four intersection routines, one case per element
  * (raytracer_fs.glsl:134-161, 93-113, 114-120, 121-131).  Host arrays; used by the parity
  * tests to pin the device arithmetic bit-for-bit against the oracle. */

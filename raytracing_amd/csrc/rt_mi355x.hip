@@ -211,6 +211,30 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     return RT_OK;
 }
 
+int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_triangles, rt_scene_info* info,
+                   char* err, size_t err_cap) {
+    rtf::Flat flat;
+    std::string msg;
+    int rc = (accel_len < 0 || n_spheres < 0 || n_triangles < 0 || (accel_len && !accel)) ? RT_ERR_INVALID_ARGUMENT
+                                                                                         : RT_OK;
+    if (rc != RT_OK) msg = "negative size or null array";
+    if (rc == RT_OK) rc = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &flat, &msg);
+    if (err && err_cap) {
+        std::strncpy(err, msg.c_str(), err_cap - 1);
+        err[err_cap - 1] = 0;
+    }
+    if (rc == RT_OK && info) {
+        std::memset(info, 0, sizeof *info);
+        info->n_nodes = (int64_t)flat.nodes.size();
+        info->n_tri_slots = (int64_t)flat.tri_slot_id.size();
+        info->n_sphere_slots = (int64_t)flat.sphere_slot_id.size();
+        info->max_depth = flat.max_depth;
+        info->lds_scene_bytes =
+            (int64_t)(flat.nodes.size() * 32 + flat.tri_slot_id.size() * 48 + flat.sphere_slot_id.size() * 16);
+    }
+    return rc;
+}
+
 int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out) {
     if (!ctx || !out) return RT_ERR_INVALID_ARGUMENT;
     if (!ctx->has_scene) return RT_ERR_NO_SCENE;

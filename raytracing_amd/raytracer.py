@@ -23,6 +23,20 @@ class RtError(RuntimeError):
         self.code = code
 
 
+def check_accel(accel, n_spheres, n_triangles):
+    """rt_check_accel: host-only validation of a serialised R-tree.  Returns the flattened sizes
+    or raises RtError (no GPU needed)."""
+    lib = N.device_lib()
+    a = np.ascontiguousarray(accel, dtype=np.float32)
+    info = N.rt_scene_info()
+    err = C.create_string_buffer(256)
+    rc = lib.rt_check_accel(N.ptr(a) if len(a) else None, len(a), int(n_spheres), int(n_triangles), C.byref(info),
+                            err, 256)
+    if rc != 0:
+        raise RtError(rc, err.value.decode())
+    return {n: int(getattr(info, n)) for n, _ in N.rt_scene_info._fields_ if n != "reserved"}
+
+
 class RayTracer:
     def __init__(self, device_id=0):
         self._lib = N.device_lib()
@@ -92,7 +106,9 @@ class RayTracer:
     def RenderGL(self, max_bounces=10, want=("rgb", "rgba8", "primary_id", "final_id"), stats=False):
         """One frame to host arrays shaped [H, W, ...], row 0 = bottom row.  Returns a dict."""
         cam = self.cameraData
-        W, H = int(cam[12]), int(cam[13])
+        # an invalid size is the library's to reject (RT_ERR_INVALID_ARGUMENT before anything is written)
+        ok = np.isfinite(cam[12:14]).all() and cam[12] >= 1 and cam[13] >= 1 and cam[12] <= 65536 and cam[13] <= 65536
+        W, H = (int(cam[12]), int(cam[13])) if ok else (1, 1)
         out = {}
         if "rgb" in want:
             out["rgb"] = np.empty((H, W, 3), np.float32)

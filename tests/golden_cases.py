@@ -1,0 +1,112 @@
+"""The fixed list of parity cases shared by the golden generator and the tests."""
+import numpy as np
+
+from raytracing_amd import host
+
+
+def _scene_cam(w, h):
+    return lambda sc: sc.camera_for(w, h)
+
+
+def _orbit(frame, w, h):
+    return lambda sc: host.camera_orbit(frame, 256, w, h)
+
+
+SOUP_SMALL = [5000, 50, 8]
+SOUP_MID = [20000, 200, 8]
+
+# full dumps (frames.npz), all oracle-sized: seconds of CPU in total
+CASES = [
+    {"id": "ts1_160x90_d10", "scene": "TestScene1", "depth": 10, "camera": _scene_cam(160, 90)},
+    {"id": "ts1_160x90_d0", "scene": "TestScene1", "depth": 0, "camera": _scene_cam(160, 90)},
+    {"id": "ts1_160x90_d2", "scene": "TestScene1", "depth": 2, "camera": _scene_cam(160, 90)},
+    {"id": "ts1_123x77_d10", "scene": "TestScene1", "depth": 10, "camera": _scene_cam(123, 77)},
+    {"id": "teapot_160x90_d1", "scene": "TeapotScene", "depth": 1, "camera": _scene_cam(160, 90)},
+    {"id": "table_f0_160x90_d8", "scene": "TeapotTable", "depth": 8, "camera": _orbit(0, 160, 90)},
+    {"id": "table_f96_160x90_d8", "scene": "TeapotTable", "depth": 8, "camera": _orbit(96, 160, 90)},
+    {"id": "soup5k_160x90_d4", "scene": "Soup", "params": SOUP_SMALL, "depth": 4, "camera": _scene_cam(160, 90)},
+]
+
+
+def big_cases():
+    """checksum-only cases at the sizes BASELINE.json names (or the largest the oracle does in seconds)"""
+    return [
+        {"id": "ts1_1280x720_d10", "scene": "TestScene1", "depth": 10, "camera": _scene_cam(1280, 720)},
+        {"id": "ts1_640x400_d10", "scene": "TestScene1", "depth": 10, "camera": _scene_cam(640, 400)},
+        {"id": "teapot_1920x1080_d1", "scene": "TeapotScene", "depth": 1, "camera": _scene_cam(1920, 1080)},
+        {"id": "table_f0_960x540_d8", "scene": "TeapotTable", "depth": 8, "camera": _orbit(0, 960, 540)},
+        {"id": "soup20k_640x360_d4", "scene": "Soup", "params": SOUP_MID, "depth": 4,
+         "camera": _scene_cam(640, 360)},
+    ]
+
+
+def _unit(v):
+    v = np.asarray(v, np.float64)
+    return (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def intersect_inputs(seed=20241110, n=4096):
+    """Deterministic per-function inputs: random cases plus the edge cases SURVEY 8a lists."""
+    g = np.random.default_rng(seed)
+    f32 = np.float32
+    out = {}
+
+    # ---- boxes: random, axis-parallel rays (inf / NaN slabs), box behind the origin, origin on a face ----
+    o = g.uniform(-5, 5, (n, 3)).astype(f32)
+    d = _unit(g.normal(size=(n, 3)))
+    lo = g.uniform(-4, 3, (n, 3)).astype(f32)
+    hi = (lo + g.uniform(0, 3, (n, 3))).astype(f32)
+    d[:256, 0] = 0.0                      # 1/0 = inf
+    d[128:384, 1] = 0.0
+    d[64:96] = np.array([0, 0, 1], f32)   # two zero components
+    d[96:128] = np.array([0, 0, -1], f32)
+    d[300:320, 2] = -0.0                  # 1/-0 = -inf
+    o[:64, 0] = lo[:64, 0]                # origin on the slab plane with zero direction: 0*inf = NaN
+    o[400:464] = (lo[400:464] - (hi[400:464] - lo[400:464]) * 3 * d[400:464]).astype(f32)  # box in front
+    o[464:528] = (hi[464:528] + (hi[464:528] - lo[464:528]) * 3 * d[464:528]).astype(f32)  # box behind
+    lo[528:560] = hi[528:560]             # degenerate (point) boxes
+    out["box_o"], out["box_d"], out["box_b"] = o, d, np.concatenate([lo, hi], 1).astype(f32)
+
+    # ---- spheres: outside, inside, tangent-ish, behind, origin on the surface ----
+    o = g.uniform(-5, 5, (n, 3)).astype(f32)
+    c = g.uniform(-3, 3, (n, 3)).astype(f32)
+    r = g.uniform(0.05, 2.0, (n, 1)).astype(f32)
+    d = _unit(c - o + g.normal(scale=0.7, size=(n, 3)))
+    o[:128] = (c[:128] + g.uniform(-0.3, 0.3, (128, 3)) * r[:128]).astype(f32)           # inside
+    d[128:256] = -d[128:256]                                                              # behind
+    o[256:384] = (c[256:384] + _unit(g.normal(size=(128, 3))) * r[256:384]).astype(f32)   # on the surface
+    d[256:320] = _unit(c[256:320] - o[256:320])                                           # pointing inwards
+    perp = _unit(np.cross(c[384:512] - o[384:512], g.normal(size=(128, 3))))
+    tgt = c[384:512] + perp * r[384:512]                                                  # grazing
+    d[384:512] = _unit(tgt - o[384:512])
+    out["sph_o"], out["sph_d"], out["sph_c"] = o, d, np.concatenate([c, r], 1).astype(f32)
+
+    # ---- planes: random, parallel (denominator exactly 0), behind ----
+    o = g.uniform(-5, 5, (n, 3)).astype(f32)
+    d = _unit(g.normal(size=(n, 3)))
+    p = g.uniform(-3, 3, (n, 3)).astype(f32)
+    nn = _unit(g.normal(size=(n, 3)))
+    nn[:128] = np.array([0, 1, 0], f32)
+    d[:64, 1] = 0.0                        # exactly parallel to the y=const plane
+    d[:64] = _unit(d[:64] * [1, 0, 1] + [1e-3, 0, 0]) * np.array([1, 0, 1], f32)
+    out["pl_o"], out["pl_d"], out["pl_p"], out["pl_n"] = o, d, p, nn
+
+    # ---- triangles: random, through vertices/edges (inclusive), parallel, behind, reversed winding ----
+    a = g.uniform(-3, 3, (n, 3)).astype(f32)
+    b = (a + g.uniform(-1.5, 1.5, (n, 3))).astype(f32)
+    cc = (a + g.uniform(-1.5, 1.5, (n, 3))).astype(f32)
+    cr = np.cross((b - a).astype(np.float64), (cc - a).astype(np.float64))
+    nrm = (cr / np.linalg.norm(cr, axis=1, keepdims=True)).astype(f32)
+    o = g.uniform(-6, 6, (n, 3)).astype(f32)
+    w = g.dirichlet([1, 1, 1], n)
+    tgt = (a * w[:, :1] + b * w[:, 1:2] + cc * w[:, 2:]).astype(f32)
+    tgt[:128] = a[:128]                                    # exactly at a vertex
+    tgt[128:256] = ((a[128:256] + b[128:256]) / 2).astype(f32)  # on an edge
+    tgt[256:512] = (tgt[256:512] + g.normal(scale=1.0, size=(256, 3))).astype(f32)  # mostly outside
+    d = _unit(tgt - o)
+    d[512:576] = -d[512:576]                               # behind
+    nrm[576:640] = -nrm[576:640]                           # winding disagrees with the stored normal
+    e = _unit(b[640:704] - a[640:704])
+    d[640:704] = e                                         # in-plane direction (denominator ~ 0)
+    out["tri_o"], out["tri_d"], out["tri_a"], out["tri_b"], out["tri_c"], out["tri_n"] = o, d, a, b, cc, nrm
+    return {k: np.ascontiguousarray(v, dtype=f32) for k, v in out.items()}

@@ -1,0 +1,71 @@
+"""GPU: band-sharded rendering and the un-permute kernel reproduce the single-GPU frame."""
+import numpy as np
+import pytest
+import torch
+
+from raytracing_amd import parallel as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h,band,world", [(160, 90, 16, 2), (123, 77, 8, 3), (320, 180, 16, 8), (64, 20, 32, 2)])
+def test_bands_assemble_to_the_full_frame(w, h, band, world, rt, scene_of):
+    sc = scene_of("TestScene1")
+    cam = sc.camera_for(w, h)
+    rt.SendPrimitivesToShader(sc)
+    rt.PrepareRenderOpenGL(cam)
+    full = rt.RenderGL(10, want=("rgba8", "final_id"))
+    dev = torch.device("cuda", 0)
+    shards = [P.ShardedFrame(rt, w, h, r, world, band, device=dev) for r in range(world)]
+    fid = [torch.full((s.pr, w), -7, dtype=torch.int32, device=dev) for s in shards]
+    for r, s in enumerate(shards):  # every "rank" renders on the one GPU, in turn
+        assert rt.local_rows(h, band, r, world) == P.local_rows(h, band, r, world)
+        assert rt.padded_rows(h, band, world) == s.pr
+        rt.render_device(cam, 10, rgba8=s.local.data_ptr(), final_id=fid[r].data_ptr(), band_rows=band, rank=r,
+                         world=world, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    gathered = torch.stack([s.local for s in shards])
+    root = shards[0]
+    root.gathered.copy_(gathered)
+    frame = root.assemble()
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), full["rgba8"])
+    assert np.array_equal(P.assemble_rows(gathered, h, band, world).cpu().numpy(), full["rgba8"])
+    ids = P.assemble_rows(torch.stack(fid), h, band, world).cpu().numpy()
+    assert np.array_equal(ids, full["final_id"])
+    # rows beyond a rank's share are never written
+    for r in range(world):
+        assert (fid[r][P.local_rows(h, band, r, world):] == -7).all()
+
+
+def test_unpermute_float3(rt):
+    w, h, band, world = 50, 37, 8, 3
+    pr = P.padded_rows(h, band, world)
+    g = torch.randn((world, pr, w, 3), device="cuda")
+    out = torch.empty((h, w, 3), device="cuda")
+    rt.unpermute_bands(g.data_ptr(), out.data_ptr(), 12, w, h, band, world)
+    torch.cuda.synchronize()
+    assert torch.equal(out, P.assemble_rows(g, h, band, world))
+
+
+def test_nccl_world_size_one(rt, scene_of):
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        sc = scene_of("TestScene1")
+        cam = sc.camera_for(96, 54)
+        rt.SendPrimitivesToShader(sc)
+        sf = P.ShardedFrame(rt, 96, 54, 0, 1, 16)
+        sf.render(cam, 10)
+        sf.gather()
+        frame = sf.assemble()
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        rt.PrepareRenderOpenGL(cam)
+        assert np.array_equal(frame.cpu().numpy(), rt.RenderGL(10, want=("rgba8",))["rgba8"])
+    finally:
+        dist.destroy_process_group()
