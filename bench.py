@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the per-pixel ray-casting hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): TeapotScene -- assets/teapot via OBJImportHelper + RTree over
+the mirror floor with TestScene1's six lights -- 1920x1080, shadows + 1 reflection bounce.
+A step renders world-size frames of a camera orbit; every frame is cut into 16-row bands dealt
+round-robin to the ranks, rendered into HBM and assembled on every rank with one RCCL
+all-gather per frame.  Per-GPU work per step is therefore one frame's worth at any N ("weak").
+Rays are counted by the reference's rule (primary + executed mirror bounces + shadow rays) with
+the reference-order kernel outside the timed region; the count is identical to the oracle's.
+
+One JSON line is printed by rank 0 (contract in the task description) with two extra objects:
+  roofline      algorithmic bytes of the reference algorithm per launch / measured kernel time
+  cpu_baseline  the CPU oracle ("port") timed single-threaded on a bounded sample of the same frame
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BAND_ROWS = 16
+
+WORKLOADS = {
+    # name: (scene, params, width, height, max_bounces)
+    "teapot_1080p_d1": ("TeapotScene", None, 1920, 1080, 1),
+    "teapot_4k_d1": ("TeapotScene", None, 3840, 2160, 1),
+    "testscene1_720p_d10": ("TestScene1", None, 1280, 720, 10),
+    "teapottable_1080p_d8": ("TeapotTable", None, 1920, 1080, 8),
+    "soup1m_4k_d4": ("Soup", [1_000_000, 10_000, 8], 3840, 2160, 4),
+    "soup100k_1080p_d4": ("Soup", [100_000, 1_000, 8], 1920, 1080, 4),
+}
+
+
+def algorithmic_bytes(stats, width, height):
+    """bytes the reference algorithm needs per frame (every candidate tested)."""
+    return (32 * stats["node_tests"] + 4 * stats["refs_read"] + 16 * stats["sphere_tests"] +
+            64 * stats["triangle_tests"] + 32 * stats["plane_tests"] + 32 * stats["material_fetches"] +
+            4 * width * height)
+
+
+def total_rays(stats):
+    return stats["primary_rays"] + stats["secondary_rays"] + stats["shadow_rays"]
+
+
+def orbit_cameras(sc, width, height, n):
+    """n cameras on a small orbit around the scene camera's own view (frame 0 = the scene camera)."""
+    from raytracing_amd import host
+    cams = [sc.camera_for(width, height)]
+    pos = sc.cameraData[0:3].astype(np.float64)
+    centre = (sc.cameraData[3:6] + (sc.cameraData[6:9] - sc.cameraData[3:6]) / 2 +
+              (sc.cameraData[9:12] - sc.cameraData[3:6]) / 2).astype(np.float64)
+    view = centre - pos
+    target = pos + view / np.linalg.norm(view) * 8.0
+    for k in range(1, n):
+        ang = 2 * np.pi * k / max(n, 8) * 0.25
+        rel = pos - target
+        c, s = np.cos(ang), np.sin(ang)
+        p = target + np.array([c * rel[0] + s * rel[2], rel[1], -s * rel[0] + c * rel[2]])
+        v = target - p
+        right = np.cross(v, [0, -1, 0])
+        cams.append(host.camera_pack(p, v, right, 1.0, 1.6, 0.9, width, height))
+    return cams
+
+
+def device_stats(rt, torch, cam, depth):
+    """Reference-rule counters of one frame from the reference-order kernel (not timed)."""
+    from raytracing_amd import _native as N
+    st = torch.zeros(16, dtype=torch.int64, device="cuda")
+    rt.render_device(cam, depth, stats=st.data_ptr(), reference_order=True,
+                     stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    v = st.cpu().numpy()
+    return {k: int(v[i]) for i, k in enumerate(N.STATS_FIELDS)}
+
+
+def time_single(rt, torch, cam, depth, width, height, steps, warmup):
+    """ms per frame of the fast kernel, device-resident RGBA8 output, HIP events on the launch stream."""
+    out = torch.empty((height, width, 4), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream()
+    for _ in range(warmup):
+        rt.render_device(cam, depth, rgba8=out.data_ptr(), stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(steps):
+        rt.render_device(cam, depth, rgba8=out.data_ptr(), stream=s.cuda_stream)
+    e1.record(s)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def cpu_baseline(sc, cam, depth, width, height, budget_s=12.0):
+    """The oracle (a C++ port of the reference algorithm; the reference itself cannot run here),
+    single-threaded, on evenly spaced full rows of the same frame, sized to ~budget_s of CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    def rows(ys, threads):
+        rays, t0 = 0, time.perf_counter()
+        for y in ys:
+            r = O.render(sc.spheresData.view(O.SPHERE_DT), sc.planesData.view(O.PLANE_DT),
+                         sc.trianglesData.view(O.TRI_DT), sc.AccelerationStructureData, sc.lightsData, cam, depth,
+                         region=(0, int(y), width, int(y) + 1), n_threads=threads, want=())
+            c = r["counters"]
+            rays += c["primary"] + c["secondary"] + c["shadow"]
+        return rays, time.perf_counter() - t0
+
+    # size the sample to ~budget_s of single-thread work: evenly spaced rows if the frame is slower
+    # than the budget, otherwise the whole frame repeated
+    probe = np.linspace(0, height - 1, 8).astype(int)
+    rays, dt = rows(probe, 1)
+    per_row = dt / len(probe)
+    if per_row * height > budget_s:
+        n_rows = int(max(8, budget_s / max(per_row, 1e-6)))
+        ys = np.unique(np.linspace(0, height - 1, n_rows).astype(int))
+        what = f"{len(ys)} evenly spaced full rows of the {width}x{height} frame"
+    else:
+        reps = int(min(64, max(1, round(budget_s / max(per_row * height, 1e-6)))))
+        ys = np.tile(np.arange(height), reps)
+        what = f"the whole {width}x{height} frame, {reps} passes"
+    rays, dt = rows(ys, 1)
+    one = rays / dt / 1e6
+    # the same sample on all host cores (one row per call, rows spread over an OpenMP team is not
+    # possible with 1-row regions, so the multi-core figure renders a band per call)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16) if os.environ.get("OMP_NUM_THREADS") is None else min(cores, int(os.environ["OMP_NUM_THREADS"]))
+    t0 = time.perf_counter()
+    band = min(height, max(cores * 4, 64))
+    y0 = (height - band) // 2
+    r = O.render(sc.spheresData.view(O.SPHERE_DT), sc.planesData.view(O.PLANE_DT), sc.trianglesData.view(O.TRI_DT),
+                 sc.AccelerationStructureData, sc.lightsData, cam, depth, region=(0, y0, width, y0 + band),
+                 n_threads=cores, want=())
+    dt_all = time.perf_counter() - t0
+    c = r["counters"]
+    allc = (c["primary"] + c["secondary"] + c["shadow"]) / dt_all / 1e6
+    return {"value": round(one, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{what} ({rays} rays, {dt:.1f} s, C++ restatement of the reference algorithm, "
+                      f"1 thread, row by row)",
+            "all_cores": {"value": round(allc, 3), "cores": cores,
+                          "sample": f"rows {y0}..{y0 + band - 1}, OpenMP row loop, {dt_all:.1f} s"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="teapot_1080p_d1", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU workloads")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--soup1m", action="store_true", help="include the 1M-triangle soup in the extras")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import RayTracer, host
+    from raytracing_amd import parallel as P
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene_name, params, W, H, depth = WORKLOADS[args.workload]
+    sc = host.make_scene(scene_name, params=params)
+    rt = RayTracer(local_rank)
+    rt.SendPrimitivesToShader(sc)
+    cams = orbit_cameras(sc, W, H, world)
+
+    # rays per step: every frame of the batch, counted by the reference-order kernel (untimed)
+    frame_stats = [device_stats(rt, torch, cam, depth) for cam in cams]
+    rays_per_step = sum(total_rays(s) for s in frame_stats)
+
+    # ---- timed region: K steps, each = `world` band-sharded frames + one all-gather per frame ----
+    stream = torch.cuda.current_stream()
+    shards = [P.ShardedFrame(rt, W, H, rank, world, BAND_ROWS) for _ in range(2)]  # double buffered
+
+    def step():
+        # frame f renders while the all-gather of frame f-1 is in flight on RCCL's stream
+        pending = [None, None]
+
+        def finish(b):
+            if pending[b] is not None:
+                pending[b].wait()          # current stream waits for the gather that used buffer b
+                shards[b].assemble(stream)  # scanline order, on every rank
+                pending[b] = None
+
+        for f, cam in enumerate(cams):
+            b = f % 2
+            finish(b)
+            shards[b].render(cam, depth, stream)
+            if world > 1:
+                pending[b] = dist.all_gather_into_tensor(shards[b].gathered.view(world * shards[b].pr, W, 4),
+                                                         shards[b].local, async_op=True)
+        finish(0)
+        finish(1)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / (args.steps * len(cams))  # per render launch, on the launch stream
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays_per_step / (elapsed / args.steps) / 1e6
+        st0 = frame_stats[0]
+        # one launch renders 1/world of a frame; algorithmic bytes scale the same way
+        alg_bytes = sum(algorithmic_bytes(s, W, H) for s in frame_stats) / len(frame_stats) / world
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if world == 1 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
+        result = {
+            "metric": "Mrays/s (primary+shadow+secondary)", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (teapot mesh fixture of the reference asset, builder-defined scene, orbit cameras)",
+            "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H,
+                       "max_bounces": depth, "lights": sc.n_lights, "triangles": len(sc.trianglesData),
+                       "frames_per_step": len(cams), "rays_per_step": rays_per_step,
+                       "sharding": f"{BAND_ROWS}-row bands round-robin over {world} rank(s), "
+                                   f"RCCL all-gather per frame" if world > 1 else "single GPU, whole frame"},
+            "ray_breakdown_frame0": {k: st0[k] for k in ("primary_rays", "secondary_rays", "shadow_rays")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_render<false>", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "algorithmic bytes of the REFERENCE algorithm (SURVEY 8d); this scene is "
+                                 "L2-resident, so the binding limit is VALU issue, not HBM"},
+        }
+
+    # ---- N = 1 only: extra workloads and the CPU baseline (outside the contract's timed region) ----
+    if world == 1 and rank == 0:
+        if not args.no_extras:
+            extras = {}
+            names = ["teapot_4k_d1", "testscene1_720p_d10", "teapottable_1080p_d8", "soup100k_1080p_d4"]
+            if args.soup1m:
+                names.append("soup1m_4k_d4")
+            for name in names:
+                if name == args.workload:
+                    continue
+                sn, pr, w, h, d = WORKLOADS[name]
+                t_build = time.perf_counter()
+                s2 = host.make_scene(sn, params=pr)
+                t_build = time.perf_counter() - t_build
+                rt.SendPrimitivesToShader(s2)
+                cam = s2.camera_for(w, h)
+                st = device_stats(rt, torch, cam, d)
+                big = name.startswith("soup")
+                ms = time_single(rt, torch, cam, d, w, h, 3 if big else 20, 1 if big else 3)
+                ab = algorithmic_bytes(st, w, h)
+                extras[name] = {"ms_per_frame": round(ms, 4), "Mrays_per_s": round(total_rays(st) / ms / 1e3, 1),
+                                "rays": total_rays(st), "algorithmic_GBps": round(ab / ms / 1e6, 1),
+                                "scene_build_s": round(t_build, 2)}
+            result["extra"] = extras
+            rt.SendPrimitivesToShader(sc)
+        if not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(sc, cams[0], depth, W, H)
+            result["gpu_over_cpu_1thread"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    rt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
