@@ -59,8 +59,9 @@ typedef struct rt_stats {
 /* Render flags */
 enum {
     RT_RENDER_DEFAULT = 0,
-    RT_RENDER_REFERENCE_ORDER = 1 /* run the exhaustive kernel that follows the reference's
-                                     candidate rules literally (used for rt_stats; slower) */
+    RT_RENDER_REFERENCE_ORDER = 1, /* run the exhaustive kernel that follows the reference's
+                                      candidate rules literally (used for rt_stats; slower) */
+    RT_RENDER_GLOBAL_MEMORY = 2    /* never use the LDS-resident kernel, even if the scene fits LDS */
 };
 
 /* Replaces GL.CreateProgram + shader load/compile/link, RayTracer.cs:49-62.
@@ -69,6 +70,16 @@ int rt_create(int device_id, rt_ctx** out);
 void rt_destroy(rt_ctx* ctx);
 /* The reference only prints GL info logs (RayTracer.cs:53-56, 1054). */
 const char* rt_last_error(const rt_ctx* ctx);
+
+/* Tuning knobs of a context (no counterpart in the reference).  Results never depend on them. */
+enum {
+    RT_OPTION_USE_LDS = 1,   /* 1: scenes whose flattened geometry fits the CU's 160 KB LDS are rendered by
+                                the LDS-resident persistent kernel; 0 (default): geometry stays in HBM/L2
+                                and is read through the scalar cache (measured faster) */
+    RT_OPTION_SUPERTILE = 2  /* edge, in 16x16-pixel tiles, of the super-tiles dealt round-robin to the
+                                XCDs by the global-memory kernel (default 4, 1..64) */
+};
+int rt_set_option(rt_ctx* ctx, int option, int value);
 
 /* Replaces RayTracer.SendPrimitivesToShader, RayTracer.cs:957-1046 (glBufferData x4 +
  * glUniform x2).  spheres: SphereStruct[n] 48 B; planes: PlaneStruct[n] 64 B; triangles:

@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-DEVICE_LIB = os.path.join(HERE, "librt_mi355x.so")
+# RT_DEVICE_LIB: development override used to A/B kernel variants in one process tree
+DEVICE_LIB = os.environ.get("RT_DEVICE_LIB") or os.path.join(HERE, "librt_mi355x.so")
 HOST_LIB = os.path.join(HERE, "librt_host.so")
 ASSET_DIR = os.path.join(HERE, "assets")
 
@@ -41,6 +42,7 @@ DEVICE_API = {
     "rt_create": (_I, [_I, C.POINTER(_VP)]),
     "rt_destroy": (None, [_VP]),
     "rt_last_error": (C.c_char_p, [_VP]),
+    "rt_set_option": (_I, [_VP, _I, _I]),
     "rt_upload_scene": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _VP, _I64, _VP, _I]),
     "rt_render": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "rt_render_device": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -18,10 +18,14 @@
 namespace rtd {
 using namespace rtm;
 
+// The hot geometry lives in ONE contiguous image of float4s, so that the same bytes can be walked
+// in HBM/L2 (GeomGlobal) or copied once into a workgroup's LDS (GeomLds):
+//   [0, 2*n_nodes)                      2 x float4 per node (rtf::FlatNode)
+//   [tri_off, tri_off + 3*n_tri_slots)  3 x float4 per triangle slot: A.xyz B.x | B.yz C.xy | C.z N.xyz
+//   [sph_off, sph_off + n_sph_slots)    1 x float4 per sphere slot: center.xyz radius
 struct DevScene {
-    const float4* nodes;        // 2 x float4 per node (rtf::FlatNode)
-    const float4* tri_geom;     // 3 x float4 per triangle slot: A.xyz B.x | B.yz C.xy | C.z N.xyz
-    const float4* sphere_geom;  // 1 x float4 per sphere slot: center.xyz radius
+    const float4* geom;
+    int32_t tri_off, sph_off, geom_float4s;
     const float4* plane_geom;   // 2 x float4 per plane: position.xyz 0 | normal.xyz 0
     const int32_t* tri_slot_id;
     const int32_t* sphere_slot_id;
@@ -30,10 +34,26 @@ struct DevScene {
     const unsigned char* tris_aos;
     const float* lights;
     int32_t n_nodes, n_planes, n_spheres, n_tris, lights_len;
+    float extent[3];  // per-axis max |coordinate| of the root box (scale of the distance-cull pad)
 };
 
-struct Ray {
-    V3 o, d;
+struct GeomGlobal {
+    const float4* base;
+    int tri_off, sph_off;
+    __device__ __forceinline__ float4 node_lo(int i) const { return base[2 * i]; }
+    __device__ __forceinline__ float4 node_hi(int i) const { return base[2 * i + 1]; }
+    __device__ __forceinline__ float4 tri(int slot, int k) const { return base[tri_off + 3 * slot + k]; }
+    __device__ __forceinline__ float4 sphere(int slot) const { return base[sph_off + slot]; }
+};
+// dynamic LDS of the LDS-resident kernel; named directly (not through a generic pointer) so that
+// every access is a ds_read_b128, never a flat load
+extern __shared__ float4 rt_lds[];
+struct GeomLds {
+    int tri_off, sph_off;
+    __device__ __forceinline__ float4 node_lo(int i) const { return rt_lds[2 * i]; }
+    __device__ __forceinline__ float4 node_hi(int i) const { return rt_lds[2 * i + 1]; }
+    __device__ __forceinline__ float4 tri(int slot, int k) const { return rt_lds[tri_off + 3 * slot + k]; }
+    __device__ __forceinline__ float4 sphere(int slot) const { return rt_lds[sph_off + slot]; }
 };
 
 constexpr float RT_FLT_BIG = 3.402823466e+38f;  // raytracer_fs.glsl:315
@@ -89,12 +109,22 @@ __device__ __forceinline__ float IntersectTriangle(V3 o, V3 d, V3 A, V3 B, V3 C,
 struct BoxRay {
     V3 o, inv;
     bool sx, sy, sz;
+    V3 padinv;  // distance-cull slack per axis in ray-parameter units (IntersectBoundingBoxCull)
 };
 __device__ __forceinline__ BoxRay make_box_ray(V3 o, V3 d) {
     BoxRay r;
     r.o = o;
     r.inv = v3(1 / d.x, 1 / d.y, 1 / d.z);
     r.sx = r.inv.x < 0, r.sy = r.inv.y < 0, r.sz = r.inv.z < 0;
+    r.padinv = v3(0, 0, 0);
+    return r;
+}
+// extent = per-axis max |coordinate| of the root box (DevScene::extent)
+__device__ __forceinline__ BoxRay make_box_ray_cull(V3 o, V3 d, V3 extent) {
+    BoxRay r = make_box_ray(o, d);
+    const float E = fmaxf(fmaxf(fabsf(o.x) + extent.x, fabsf(o.y) + extent.y), fabsf(o.z) + extent.z);
+    const float pad = E * 0.0078125f;  // 2^-7 of the scale of every coordinate the ray can meet
+    r.padinv = v3(pad * fabsf(r.inv.x), pad * fabsf(r.inv.y), pad * fabsf(r.inv.z));
     return r;
 }
 __device__ __forceinline__ bool IntersectBoundingBox(const BoxRay& r, float4 lo, float4 hi) {
@@ -111,12 +141,45 @@ __device__ __forceinline__ bool IntersectBoundingBox(const BoxRay& r, float4 lo,
     return true;
 }
 
+// The reference's test above, followed by a conservative distance cull that is NOT in the
+// reference: the node is also skipped when no primitive inside it can be accepted by the
+// caller's window t_lo < t < t_hi (closest hit: minDistance and the best t so far; shadow ray:
+// epsilon and the distance to the light).
+//
+// Why this cannot change a result (DESIGN.md "distance cull"): an accepted hit has a computed
+// parameter t_c whose point X_c = o + t_c*d lies within a distance `pad` of the primitive, hence
+// inside the node's box grown by `pad` on every side, hence t_c lies inside the slab interval of
+// the grown box, [max_i(tnear_i - pad*|inv_i|), min_i(tfar_i + pad*|inv_i|)].  For a triangle the
+// off-plane error of X_c is a few ulps of the scene scale E and its in-plane position passed the
+// edge tests; for a sphere the error of t_c is bounded by sqrt(8*4*eps)*(|o-c|+r) < 2.8e-3*E (the
+// worst case is a grazing ray, discriminant ~ 0).  pad = E/128 = 7.8e-3*E covers both.  NaN slab
+// values (zero direction components) make every comparison false: no cull, as in the reference.
+__device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4 lo, float4 hi, float t_lo,
+                                                         float t_hi) {
+    const float txn = ((r.sx ? hi.x : lo.x) - r.o.x) * r.inv.x;
+    const float txf = ((r.sx ? lo.x : hi.x) - r.o.x) * r.inv.x;
+    const float tyn = ((r.sy ? hi.y : lo.y) - r.o.y) * r.inv.y;
+    const float tyf = ((r.sy ? lo.y : hi.y) - r.o.y) * r.inv.y;
+    if ((txn > tyf) || (tyn > txf)) return false;
+    const float mn = (tyn > txn) ? tyn : txn;
+    const float mf = (tyf < txf) ? tyf : txf;
+    const float tzn = ((r.sz ? hi.z : lo.z) - r.o.z) * r.inv.z;
+    const float tzf = ((r.sz ? lo.z : hi.z) - r.o.z) * r.inv.z;
+    if ((mn > tzf) || (tzn > mf)) return false;
+    // ---- not in the reference: padded-interval cull ----
+    const float en = fmaxf(fmaxf(txn - r.padinv.x, tyn - r.padinv.y), tzn - r.padinv.z);
+    const float ef = fminf(fminf(txf + r.padinv.x, tyf + r.padinv.y), tzf + r.padinv.z);
+    if ((en > t_hi) || (ef < t_lo)) return false;
+    return true;
+}
+
 // ---- geometry fetch ----------------------------------------------------------------------
 struct TriG {
     V3 A, B, C, N;
 };
-__device__ __forceinline__ TriG load_tri(const float4* g, int slot) {
-    float4 q0 = g[3 * slot], q1 = g[3 * slot + 1], q2 = g[3 * slot + 2];
+template <class G>
+__device__ __forceinline__ TriG load_tri(const G& g, int slot) {
+    const float4 q0 = g.tri(slot, 0), q1 = g.tri(slot, 1), q2 = g.tri(slot, 2);
     TriG t;
     t.A = v3(q0.x, q0.y, q0.z);
     t.B = v3(q0.w, q1.x, q1.y);

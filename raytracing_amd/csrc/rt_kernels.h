@@ -1,5 +1,6 @@
-// rt_kernels.h -- the gfx950 kernels: per-pixel render (reference-order and fast variants),
-// geometry re-layout, band un-permute and the per-function evaluators.
+// rt_kernels.h -- the gfx950 kernels: per-pixel render (reference-order, fast-global and
+// LDS-resident persistent variants), geometry re-layout, band un-permute and the per-function
+// evaluators.
 #pragma once
 #include "rt_device.h"
 
@@ -13,14 +14,14 @@ enum { C_PRIMARY, C_SECONDARY, C_SHADOW, C_NODE, C_REFS, C_SPHERE, C_PLANE, C_TR
 // ------------------------------------------------------------------------------------------
 // Stackless fixed-order traversal (rt_flatten.h).  kinds: bit 0 = test sphere leaves,
 // bit 1 = test triangle leaves.  COUNT adds the reference's node/ref counters.
+// G is the geometry source: GeomGlobal (HBM/L2) or GeomLds (workgroup LDS).
 // ------------------------------------------------------------------------------------------
-template <bool COUNT, class LeafSphere, class LeafTri>
-__device__ __forceinline__ void walk(const DevScene& S, const BoxRay& br, int kinds, bool count_nodes,
+template <bool COUNT, class G, class LeafSphere, class LeafTri>
+__device__ __forceinline__ void walk(const G& g, int n_nodes, const BoxRay& br, int kinds, bool count_nodes,
                                      uint32_t* cnt, LeafSphere&& on_sphere, LeafTri&& on_tri) {
     int i = 0;
-    const int n = S.n_nodes;
-    while (i < n) {
-        const float4 lo = S.nodes[2 * i], hi = S.nodes[2 * i + 1];
+    while (i < n_nodes) {
+        const float4 lo = g.node_lo(i), hi = g.node_hi(i);
         const uint32_t meta = __float_as_uint(hi.w);
         if (COUNT && count_nodes && !(meta & rtf::META_CONT)) cnt[C_NODE]++;
         if (!IntersectBoundingBox(br, lo, hi)) {
@@ -49,16 +50,69 @@ __device__ __forceinline__ void walk(const DevScene& S, const BoxRay& br, int ki
 }
 
 // ------------------------------------------------------------------------------------------
+// Wave-cooperative form of the same walk (the fast kernels).
+//
+// The visit order of the flattened tree does not depend on the ray, so the lanes of a wavefront
+// that enter the walk together can share ONE node index: a node is visited when ANY lane's ray
+// hits its box (__ballot), and a lane whose ray misses sits out that subtree (its `resume` index
+// is set to the node's skip link).  Each lane still sees exactly the nodes and primitives its own
+// ray reaches in the reference, in the same order, so results are unchanged; what changes is the
+// memory side: the node index and leaf slots are wave-uniform, so a node or a triangle is ONE
+// scalar load (geometry in HBM/L2) or ONE LDS broadcast read per wave instead of a 64-lane
+// gather of 2 KB.  Lanes that are finished (any-hit found) pass `done` and stop taking part;
+// the walk ends early when no lane is left.  Convergence: every lane that enters stays in the
+// loop until the wave-uniform exit, so the ballots are well defined under divergent callers.
+// ------------------------------------------------------------------------------------------
+// t_lo / t_hi(): the caller's acceptance window for the distance cull (IntersectBoundingBoxCull);
+// t_hi is re-read at every node because a closest-hit query narrows it as it goes.
+template <class G, class LeafSphere, class LeafTri, class Done, class THi>
+__device__ __forceinline__ void wave_walk(const G& g, int n_nodes, const BoxRay& br, bool alive, float t_lo,
+                                          THi&& t_hi, LeafSphere&& on_sphere, LeafTri&& on_tri, Done&& done) {
+    int i = 0;
+    int resume = alive ? 0 : 0x7FFFFFFF;  // first node index at which this lane takes part again
+    if (__ballot(alive) == 0ull) return;
+    while (i < n_nodes) {
+        i = __builtin_amdgcn_readfirstlane(i);
+        const float4 lo = g.node_lo(i), hi = g.node_hi(i);
+        const uint32_t meta = __float_as_uint(hi.w);
+        const int skip = __float_as_int(lo.w);
+        const bool active = i >= resume;
+        const bool hit = active && IntersectBoundingBoxCull(br, lo, hi, t_lo, t_hi());
+        if (active && !hit) resume = skip;
+        if (__ballot(hit) == 0ull) {
+            i = skip;
+            continue;
+        }
+        const int kind = (meta >> 29) & 3;
+        if (kind != rtf::KIND_BRANCH) {
+            const int count = (meta >> 24) & 31;
+            const int first = meta & 0xFFFFFF;
+            if (kind == rtf::KIND_SPHERE) {
+                for (int k = 0; k < count; k++)
+                    if (hit) on_sphere(first + k);
+            } else {
+                for (int k = 0; k < count; k++)
+                    if (hit) on_tri(first + k);
+            }
+            if (done()) resume = 0x7FFFFFFF;
+            if (__ballot(resume != 0x7FFFFFFF) == 0ull) return;
+        }
+        i++;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // FindClosestIntersection, raytracer_fs.glsl:241-297
 // ------------------------------------------------------------------------------------------
-template <bool REF>
-__device__ __forceinline__ Closest find_closest(const DevScene& S, V3 o, V3 d, float minDistance, uint32_t* cnt) {
+template <bool REF, class G>
+__device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V3 o, V3 d, float minDistance,
+                                                uint32_t* cnt) {
     Closest h = fresh_closest();
-    const BoxRay br = make_box_ray(o, d);
+    const BoxRay br = REF ? make_box_ray(o, d) : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]));
     auto sphere = [&](int slot) {
-        const float4 g = S.sphere_geom[slot];
+        const float4 s = g.sphere(slot);
         if (REF) cnt[C_SPHERE]++;
-        const float4 r = IntersectSphere(o, d, v3(g.x, g.y, g.z), g.w);
+        const float4 r = IntersectSphere(o, d, v3(s.x, s.y, s.z), s.w);
         if (closer(r.w, 0, minDistance, h)) {
             if (REF) cnt[C_MAT]++;
             h.t = r.w, h.kind = 0, h.index = slot, h.n = v3(r.x, r.y, r.z);
@@ -66,9 +120,9 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, V3 o, V3 d, f
         return false;
     };
     auto tri = [&](int slot) {
-        const TriG g = load_tri(S.tri_geom, slot);
+        const TriG tg = load_tri(g, slot);
         if (REF) cnt[C_TRI]++;
-        const float t = IntersectTriangle(o, d, g.A, g.B, g.C, g.N);
+        const float t = IntersectTriangle(o, d, tg.A, tg.B, tg.C, tg.N);
         if (closer(t, 2, minDistance, h)) {
             if (REF) cnt[C_MAT]++;
             h.t = t, h.kind = 2, h.index = slot;
@@ -88,12 +142,12 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, V3 o, V3 d, f
     };
     if (REF) {
         // literal candidate order: spheres, planes, triangles (two walks; nodes counted once)
-        walk<true>(S, br, 1, true, cnt, sphere, tri);
+        walk<true>(g, S.n_nodes, br, 1, true, cnt, sphere, tri);
         planes();
-        walk<true>(S, br, 2, false, cnt, sphere, tri);
+        walk<true>(g, S.n_nodes, br, 2, false, cnt, sphere, tri);
     } else {
         planes();
-        walk<false>(S, br, 3, false, cnt, sphere, tri);
+        wave_walk(g, S.n_nodes, br, true, minDistance, [&] { return h.t; }, sphere, tri, [] { return false; });
     }
     return h;
 }
@@ -101,15 +155,16 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, V3 o, V3 d, f
 // ------------------------------------------------------------------------------------------
 // ObjectInWayOfLight, raytracer_fs.glsl:200-240
 // ------------------------------------------------------------------------------------------
-template <bool REF>
-__device__ __forceinline__ bool object_in_way(const DevScene& S, float distanceToLight, V3 o, V3 d, uint32_t* cnt) {
-    const BoxRay br = make_box_ray(o, d);
+template <bool REF, class G>
+__device__ __forceinline__ bool object_in_way(const DevScene& S, const G& g, float distanceToLight, V3 o, V3 d,
+                                              uint32_t* cnt) {
+    const BoxRay br = REF ? make_box_ray(o, d) : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]));
     bool blocked = false;
     auto in_range = [&](float t) { return t > RT_EPSILON && t < distanceToLight; };
     auto tri = [&](int slot) {
-        const TriG g = load_tri(S.tri_geom, slot);
+        const TriG tg = load_tri(g, slot);
         if (REF) cnt[C_TRI]++;
-        if (in_range(IntersectTriangle(o, d, g.A, g.B, g.C, g.N))) blocked = true;
+        if (in_range(IntersectTriangle(o, d, tg.A, tg.B, tg.C, tg.N))) blocked = true;
         return blocked;  // stop at the first blocker
     };
     auto plane_blocks = [&]() {
@@ -126,26 +181,33 @@ __device__ __forceinline__ bool object_in_way(const DevScene& S, float distanceT
         // first blocker: keep walking for the node counters, stop testing once blocked
         auto sphere = [&](int slot) {
             if (!blocked) {
-                const float4 g = S.sphere_geom[slot];
+                const float4 s = g.sphere(slot);
                 cnt[C_SPHERE]++;
-                if (in_range(IntersectSphereT(o, d, v3(g.x, g.y, g.z), g.w))) blocked = true;
+                if (in_range(IntersectSphereT(o, d, v3(s.x, s.y, s.z), s.w))) blocked = true;
             }
             return false;
         };
-        walk<true>(S, br, 1, true, cnt, sphere, tri);
+        walk<true>(g, S.n_nodes, br, 1, true, cnt, sphere, tri);
         if (blocked) return true;
         if (plane_blocks()) return true;
-        walk<true>(S, br, 2, false, cnt, sphere, tri);
+        walk<true>(g, S.n_nodes, br, 2, false, cnt, sphere, tri);
         return blocked;
     } else {
         // any-hit is order independent: cheapest test first, leave at the first blocker
-        if (plane_blocks()) return true;
+        // (a lane that is already blocked sits the rest of the walk out)
+        blocked = plane_blocks();
         auto sphere = [&](int slot) {
-            const float4 g = S.sphere_geom[slot];
-            if (in_range(IntersectSphereT(o, d, v3(g.x, g.y, g.z), g.w))) blocked = true;
-            return blocked;
+            if (blocked) return;
+            const float4 s = g.sphere(slot);
+            if (in_range(IntersectSphereT(o, d, v3(s.x, s.y, s.z), s.w))) blocked = true;
         };
-        walk<false>(S, br, 3, false, cnt, sphere, tri);
+        auto tri_any = [&](int slot) {
+            if (blocked) return;
+            const TriG tg = load_tri(g, slot);
+            if (in_range(IntersectTriangle(o, d, tg.A, tg.B, tg.C, tg.N))) blocked = true;
+        };
+        wave_walk(g, S.n_nodes, br, !blocked, RT_EPSILON, [&] { return distanceToLight; }, sphere, tri_any,
+                  [&] { return blocked; });
         return blocked;
     }
 }
@@ -158,24 +220,16 @@ struct PixelOut {
     int primary_id, final_id, bounces;
 };
 
-template <bool REF>
-__device__ __forceinline__ V3 light_loop_diffuse(const DevScene& S, V3 hitPos, const Surface& sf, uint32_t* cnt) {
-    // raytracer_fs.glsl:342-356 (mirror surfaces with a diffuse component, unflipped normal)
-    V3 combined = sf.diffuse * v3(0.1f, 0.1f, 0.1f);
-    for (int l = 0; l < S.lights_len; l += 6) {
-        const V3 lightPos = v3(S.lights[l], S.lights[l + 1], S.lights[l + 2]);
-        const float dist = length(lightPos - hitPos);
-        const V3 L = normalize(lightPos - hitPos);
-        if (!object_in_way<REF>(S, dist, hitPos, L, cnt)) {
-            const V3 lightColor = v3(S.lights[l + 3], S.lights[l + 4], S.lights[l + 5]);
-            combined = combined + 1.0f / (dist * dist) * lightColor * sf.diffuse * max0(dot(sf.normal, L));
-        }
-    }
-    return combined;
+__device__ __forceinline__ Surface no_surface() {
+    // raytracer_fs.glsl:315-323, 371-376
+    Surface sf;
+    sf.diffuse = v3(0, 0, 0), sf.specular = v3(0, 0, 0), sf.normal = v3(0, 0, 0);
+    sf.specularity = 1.0f, sf.pure = false, sf.id = -1;
+    return sf;
 }
 
-template <bool REF>
-__device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const float* cam, float px, float py,
+template <bool REF, class G>
+__device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, const float* cam, float px, float py,
                                                 int maxBounces, uint32_t* cnt) {
     const float width = cam[12], height = cam[13];
     const V3 bottomLeft = v3(cam[3], cam[4], cam[5]);
@@ -186,11 +240,8 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const float* 
         (bottomLeft + (px / width) * (bottomRight - bottomLeft) + (py / height) * (topLeft - bottomLeft)) - rayOrigin);
 
     if (REF) cnt[C_PRIMARY]++;
-    Closest h = find_closest<REF>(S, rayOrigin, rayDirection, 0.0f, cnt);
-    Surface sf;
-    sf.diffuse = v3(0, 0, 0), sf.specular = v3(0, 0, 0), sf.normal = v3(0, 0, 0);
-    sf.specularity = 1.0f, sf.pure = false, sf.id = -1;
-    if (h.kind != 3) sf = resolve_surface(S, h);
+    Closest h = find_closest<REF>(S, g, rayOrigin, rayDirection, 0.0f, cnt);
+    Surface sf = (h.kind != 3) ? resolve_surface(S, h) : no_surface();
     PixelOut out;
     out.primary_id = sf.id;
 
@@ -201,7 +252,17 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const float* 
         if (REF) cnt[C_SECONDARY]++;
         const V3 hitPos = rayOrigin + h.t * rayDirection;
         if (sf.diffuse.x != 0 || sf.diffuse.y != 0 || sf.diffuse.z != 0) {
-            const V3 combined = light_loop_diffuse<REF>(S, hitPos, sf, cnt);
+            // raytracer_fs.glsl:342-357 (mirror with a diffuse component; the normal is not flipped here)
+            V3 combined = sf.diffuse * v3(0.1f, 0.1f, 0.1f);
+            for (int l = 0; l < S.lights_len; l += 6) {
+                const V3 lightPos = v3(S.lights[l], S.lights[l + 1], S.lights[l + 2]);
+                const float dist = length(lightPos - hitPos);
+                const V3 L = normalize(lightPos - hitPos);
+                if (!object_in_way<REF>(S, g, dist, hitPos, L, cnt)) {
+                    const V3 lightColor = v3(S.lights[l + 3], S.lights[l + 4], S.lights[l + 5]);
+                    combined = combined + 1.0f / (dist * dist) * lightColor * sf.diffuse * max0(dot(sf.normal, L));
+                }
+            }
             finalColor = finalColor + combined * mult;
         }
         mult = mult * sf.specular;
@@ -210,10 +271,8 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const float* 
         const V3 refl = normalize(rayDirection - 2 * dot(rayDirection, n) * n);
         rayOrigin = hitPos;
         rayDirection = refl;
-        h = find_closest<REF>(S, rayOrigin, rayDirection, RT_EPSILON, cnt);
-        sf.diffuse = v3(0, 0, 0), sf.specular = v3(0, 0, 0), sf.normal = v3(0, 0, 0);
-        sf.specularity = 1.0f, sf.pure = false, sf.id = -1;
-        if (h.kind != 3) sf = resolve_surface(S, h);
+        h = find_closest<REF>(S, g, rayOrigin, rayDirection, RT_EPSILON, cnt);
+        sf = (h.kind != 3) ? resolve_surface(S, h) : no_surface();
         bounces++;
     }
     out.bounces = bounces;
@@ -230,7 +289,7 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const float* 
         const V3 lightPos = v3(S.lights[l], S.lights[l + 1], S.lights[l + 2]);
         const float dist = length(lightPos - hitPos);
         const V3 L = normalize(lightPos - hitPos);
-        if (!object_in_way<REF>(S, dist, hitPos, L, cnt)) {
+        if (!object_in_way<REF>(S, g, dist, hitPos, L, cnt)) {
             const V3 lightColor = v3(S.lights[l + 3], S.lights[l + 4], S.lights[l + 5]);
             if (dot(n, rayDirection) > 0.0f) n = -n;
             const V3 R = normalize(L - 2 * dot(L, n) * n);
@@ -257,34 +316,63 @@ struct RenderArgs {
     int width, height;   // full frame
     int local_rows;      // rows this launch renders
     int band_rows, rank, world;
-    int tiles_x, n_tiles;
+    int tiles_x, tiles_y, supertile;
     float* rgb;
     uint32_t* rgba8;
     int32_t* primary_id;
     int32_t* final_id;
     int32_t* bounces;
     unsigned long long* stats;  // C_N counters, accumulated (reference-order kernel only)
+    // LDS-resident persistent kernel only: ticket counter and this launch's first ticket
+    unsigned int* ticket;
+    unsigned int ticket_base;
 };
 
-// blocks b and b+8 share an XCD (round-robin dispatch): give each XCD one contiguous run of
-// tiles so that its L2 keeps the part of the tree its screen region walks.  Bijective for any
-// n (cdna guide T1).
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-    const int q = n / 8, r = n % 8, x = b % 8;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+__device__ __forceinline__ void store_pixel(const RenderArgs& a, int x, int r, const PixelOut& p) {
+    const size_t i = (size_t)r * a.width + x;
+    if (a.rgb) a.rgb[3 * i] = p.rgb.x, a.rgb[3 * i + 1] = p.rgb.y, a.rgb[3 * i + 2] = p.rgb.z;
+    if (a.rgba8) a.rgba8[i] = quantise(p.rgb.x) | (quantise(p.rgb.y) << 8) | (quantise(p.rgb.z) << 16) | 0xFF000000u;
+    if (a.primary_id) a.primary_id[i] = p.primary_id;
+    if (a.final_id) a.final_id[i] = p.final_id;
+    if (a.bounces) a.bounces[i] = p.bounces;
+}
+// local row (band-sharded frames, rt_mi355x.h) -> global row
+__device__ __forceinline__ int global_row(const RenderArgs& a, int r) {
+    return ((r / a.band_rows) * a.world + a.rank) * a.band_rows + r % a.band_rows;
+}
+
+// Block -> tile mapping.  Blocks b and b+8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md);
+// block b is the j-th block of XCD slot x (x = b % 8, j = b / 8).  The image is cut into
+// super-tiles of ST x ST tiles that are dealt round-robin to the XCD slots: consecutive blocks of
+// one slot walk one super-tile (so the XCD's L2 keeps the subtree that screen region walks), and
+// every slot gets super-tiles from all over the image (so sky, floor and mesh work is balanced
+// across XCDs -- one contiguous run of tiles per XCD left the sky XCDs idle: 30 % wave-slot use).
+// Returns false for the padding blocks of a partial super-tile.
+__device__ __forceinline__ bool block_to_tile(int b, int st, int tiles_x, int tiles_y, int* tx, int* ty) {
+    const int x = b & 7, j = b >> 3;
+    const int per = st * st;
+    const int super = (j / per) * 8 + x;
+    const int in = j % per;
+    const int sx_n = (tiles_x + st - 1) / st;
+    const int sx = super % sx_n, sy = super / sx_n;
+    *tx = sx * st + in % st;
+    *ty = sy * st + in / st;
+    return *tx < tiles_x && *ty < tiles_y;
 }
 
 constexpr int TILE = 16;  // 16x16 pixels per 256-thread workgroup, 8x8 per wave
 
+// ---- geometry in HBM/L2: one thread per pixel, one 16x16 tile per workgroup -------------------
 template <bool REF>
 __global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
-    const int tile = xcd_remap(blockIdx.x, a.n_tiles);
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    int tx, ty;
+    const bool in_image = block_to_tile(blockIdx.x, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int r = ty * TILE + (wave >> 1) * 8 + (lane >> 3);           // local row
-    const int y = ((r / a.band_rows) * a.world + a.rank) * a.band_rows + r % a.band_rows;  // global row
-    const bool live = x < a.width && r < a.local_rows && y < a.height;
+    const int r = ty * TILE + (wave >> 1) * 8 + (lane >> 3);  // local row
+    const int y = global_row(a, r);
+    const bool live = in_image && x < a.width && r < a.local_rows && y < a.height;
+    const GeomGlobal g{a.scene.geom, a.scene.tri_off, a.scene.sph_off};
 
     uint32_t cnt[C_N];
     if (REF) {
@@ -292,14 +380,8 @@ __global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
         for (int k = 0; k < C_N; k++) cnt[k] = 0;
     }
     if (live) {
-        const PixelOut p = shade_pixel<REF>(a.scene, a.cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, cnt);
-        const size_t i = (size_t)r * a.width + x;
-        if (a.rgb) a.rgb[3 * i] = p.rgb.x, a.rgb[3 * i + 1] = p.rgb.y, a.rgb[3 * i + 2] = p.rgb.z;
-        if (a.rgba8)
-            a.rgba8[i] = quantise(p.rgb.x) | (quantise(p.rgb.y) << 8) | (quantise(p.rgb.z) << 16) | 0xFF000000u;
-        if (a.primary_id) a.primary_id[i] = p.primary_id;
-        if (a.final_id) a.final_id[i] = p.final_id;
-        if (a.bounces) a.bounces[i] = p.bounces;
+        const PixelOut p = shade_pixel<REF>(a.scene, g, a.cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, cnt);
+        store_pixel(a, x, r, p);
     }
     if (REF && a.stats) {
 #pragma unroll
@@ -307,6 +389,40 @@ __global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
             unsigned long long v = cnt[k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0 && v) atomicAdd(&a.stats[k], v);
+        }
+    }
+}
+
+// ---- geometry in LDS: persistent workgroups, waves pull 8x8 tiles from a ticket counter --------
+// A scene whose flattened geometry fits the CU's 160 KB LDS is copied there once per workgroup
+// (one 1024-thread workgroup per CU, grid = number of CUs).  Every node/triangle fetch of the
+// traversal is then a ds_read_b128 instead of a scattered 16-byte gather through the vector
+// memory pipeline, which is what bounds k_render on such scenes (profiles/).
+// Work distribution: each wave draws tickets (one 8x8 pixel tile each) from one device-scope
+// counter until the frame is exhausted -- dynamic balance between sky and mesh tiles, and every
+// wave reaches the exit condition (ticket >= n_tiles), so the grid always drains.  The counter is
+// never reset: the host passes the first ticket of this launch (ticket_base) and advances it by
+// n_tiles + number of waves, which is exactly what the launch consumes.
+constexpr int LDS_BLOCK = 1024;
+__global__ __launch_bounds__(LDS_BLOCK) void k_render_lds(const RenderArgs a) {
+    for (int i = threadIdx.x; i < a.scene.geom_float4s; i += LDS_BLOCK) rt_lds[i] = a.scene.geom[i];
+    __syncthreads();
+    const GeomLds g{a.scene.tri_off, a.scene.sph_off};
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (a.width + 7) >> 3, tiles_y = (a.local_rows + 7) >> 3;
+    const unsigned int n_tiles = (unsigned int)(tiles_x * tiles_y);
+    for (;;) {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(a.ticket, 1u) - a.ticket_base;
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= n_tiles) break;
+        const int x = (int)(t % tiles_x) * 8 + (lane & 7);
+        const int r = (int)(t / tiles_x) * 8 + (lane >> 3);
+        const int y = global_row(a, r);
+        if (x < a.width && r < a.local_rows && y < a.height) {
+            const PixelOut p =
+                shade_pixel<false>(a.scene, g, a.cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, nullptr);
+            store_pixel(a, x, r, p);
         }
     }
 }

@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,11 +27,18 @@ struct rt_ctx {
     int device = 0;
     std::string error;
     bool has_scene = false;
+    int supertile = 4;  // tiles per super-tile edge (RT_SUPERTILE overrides; see block_to_tile)
     DevScene scene{};
     rt_scene_info info{};
     // scene buffers
-    DevBuf nodes, tri_geom, sphere_geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos,
-        tris_aos, lights;
+    DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights;
+    // LDS-resident persistent kernel (k_render_lds)
+    DevBuf ticket;
+    unsigned int ticket_base = 0;
+    int n_cus = 256;
+    bool lds_capable = false;   // the scene's geometry image fits the CU's LDS
+    int lds_limit = 160 * 1024;  // bytes of dynamic LDS one workgroup may take (160 KB per CU)
+    bool allow_lds = false;     // opt-in (RT_OPTION_USE_LDS): measured slower than the scalar-load walk
     // frame buffers of rt_render (grow only)
     DevBuf fb_rgb, fb_rgba8, fb_pid, fb_fid, fb_stats;
     // scratch of the evaluators
@@ -112,10 +121,30 @@ int rt_create(int device_id, rt_ctx** out) {
     if (e != hipSuccess || device_id < 0 || device_id >= n) return RT_ERR_DEVICE;
     rt_ctx* ctx = new rt_ctx();
     ctx->device = device_id;
+    if (const char* v = getenv("RT_SUPERTILE")) {
+        const int st = atoi(v);
+        if (st >= 1 && st <= 64) ctx->supertile = st;
+    }
     e = hipSetDevice(device_id);
     if (e != hipSuccess) {
         delete ctx;
         return RT_ERR_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        if (prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount;
+        if (prop.maxSharedMemoryPerMultiProcessor > 0)
+            ctx->lds_limit = std::min<int>(ctx->lds_limit, (int)prop.maxSharedMemoryPerMultiProcessor);
+    }
+    if (const char* v = getenv("RT_USE_LDS")) ctx->allow_lds = atoi(v) != 0;
+    // the persistent kernel's ticket counter: zeroed once, never reset (rt_kernels.h)
+    if (hipMalloc(&ctx->ticket.p, 256) != hipSuccess || hipMemset(ctx->ticket.p, 0, 256) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_render_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            ctx->lds_limit) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->allow_lds = false;  // the global-memory kernel needs none of this
+    } else {
+        ctx->ticket.bytes = 256;
     }
     *out = ctx;
     return RT_OK;
@@ -125,12 +154,26 @@ void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    DevBuf* all[] = {&ctx->nodes,      &ctx->tri_geom,   &ctx->sphere_geom, &ctx->plane_geom, &ctx->tri_slot_id,
-                     &ctx->sphere_slot_id, &ctx->spheres_aos, &ctx->planes_aos, &ctx->tris_aos, &ctx->lights,
-                     &ctx->fb_rgb,     &ctx->fb_rgba8,   &ctx->fb_pid,      &ctx->fb_fid,     &ctx->fb_stats};
+    DevBuf* all[] = {&ctx->geom,       &ctx->plane_geom, &ctx->tri_slot_id, &ctx->sphere_slot_id, &ctx->spheres_aos,
+                     &ctx->planes_aos, &ctx->tris_aos,   &ctx->lights,      &ctx->ticket,         &ctx->fb_rgb,
+                     &ctx->fb_rgba8,   &ctx->fb_pid,     &ctx->fb_fid,      &ctx->fb_stats};
     for (DevBuf* b : all) release(*b);
     for (DevBuf& b : ctx->ev) release(b);
     delete ctx;
+}
+
+int rt_set_option(rt_ctx* ctx, int option, int value) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    switch (option) {
+        case RT_OPTION_USE_LDS:
+            ctx->allow_lds = value != 0 && ctx->ticket.p != nullptr;
+            return RT_OK;
+        case RT_OPTION_SUPERTILE:
+            if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "supertile must be 1..64");
+            ctx->supertile = value;
+            return RT_OK;
+    }
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option");
 }
 
 const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
@@ -156,24 +199,30 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     if ((rc = upload(ctx, ctx->planes_aos, planes, (size_t)n_planes * 64))) return rc;
     if ((rc = upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96))) return rc;
     if ((rc = upload(ctx, ctx->lights, lights, (size_t)lights_len * 4))) return rc;
-    if ((rc = upload(ctx, ctx->nodes, flat.nodes.data(), flat.nodes.size() * sizeof(rtf::FlatNode)))) return rc;
     if ((rc = upload(ctx, ctx->tri_slot_id, flat.tri_slot_id.data(), flat.tri_slot_id.size() * 4))) return rc;
     if ((rc = upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), flat.sphere_slot_id.size() * 4)))
         return rc;
     const int n_ts = (int)flat.tri_slot_id.size(), n_ss = (int)flat.sphere_slot_id.size();
-    if ((rc = ensure(ctx, ctx->tri_geom, (size_t)n_ts * 48))) return rc;
-    if ((rc = ensure(ctx, ctx->sphere_geom, (size_t)n_ss * 16))) return rc;
+    // one contiguous geometry image: nodes | triangle slots | sphere slots (rt_device.h)
+    const size_t tri_off = flat.nodes.size() * 2, sph_off = tri_off + (size_t)n_ts * 3;
+    const size_t geom_f4 = sph_off + (size_t)n_ss;
+    if (geom_f4 >= (size_t)INT32_MAX / 2) return fail(ctx, RT_ERR_TOO_LARGE, "geometry image too large");
+    if ((rc = ensure(ctx, ctx->geom, geom_f4 * 16))) return rc;
+    if (!flat.nodes.empty())
+        HIP_TRY(ctx, hipMemcpy(ctx->geom.p, flat.nodes.data(), flat.nodes.size() * 32, hipMemcpyHostToDevice));
     if ((rc = ensure(ctx, ctx->plane_geom, (size_t)n_planes * 32))) return rc;
+    float4* const tri_geom = (float4*)ctx->geom.p + tri_off;
+    float4* const sphere_geom = (float4*)ctx->geom.p + sph_off;
 
     // GPU re-layout: AoS upload -> traversal-order geometry slots
     if (n_ts)
         hipLaunchKernelGGL(k_gather_tris, dim3((n_ts + 255) / 256), dim3(256), 0, 0,
-                           (const unsigned char*)ctx->tris_aos.p, (const int32_t*)ctx->tri_slot_id.p,
-                           (float4*)ctx->tri_geom.p, n_ts);
+                           (const unsigned char*)ctx->tris_aos.p, (const int32_t*)ctx->tri_slot_id.p, tri_geom,
+                           n_ts);
     if (n_ss)
         hipLaunchKernelGGL(k_gather_spheres, dim3((n_ss + 255) / 256), dim3(256), 0, 0,
                            (const unsigned char*)ctx->spheres_aos.p, (const int32_t*)ctx->sphere_slot_id.p,
-                           (float4*)ctx->sphere_geom.p, n_ss);
+                           sphere_geom, n_ss);
     if (n_planes)
         hipLaunchKernelGGL(k_gather_planes, dim3((n_planes + 255) / 256), dim3(256), 0, 0,
                            (const unsigned char*)ctx->planes_aos.p, (float4*)ctx->plane_geom.p, n_planes);
@@ -181,9 +230,10 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     HIP_TRY(ctx, hipDeviceSynchronize());
 
     DevScene& s = ctx->scene;
-    s.nodes = (const float4*)ctx->nodes.p;
-    s.tri_geom = (const float4*)ctx->tri_geom.p;
-    s.sphere_geom = (const float4*)ctx->sphere_geom.p;
+    s.geom = (const float4*)ctx->geom.p;
+    s.tri_off = (int32_t)tri_off;
+    s.sph_off = (int32_t)sph_off;
+    s.geom_float4s = (int32_t)geom_f4;
     s.plane_geom = (const float4*)ctx->plane_geom.p;
     s.tri_slot_id = (const int32_t*)ctx->tri_slot_id.p;
     s.sphere_slot_id = (const int32_t*)ctx->sphere_slot_id.p;
@@ -196,6 +246,12 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     s.n_spheres = n_spheres;
     s.n_tris = n_triangles;
     s.lights_len = lights_len;
+    for (int k = 0; k < 3; k++) s.extent[k] = 0.0f;
+    if (!flat.nodes.empty()) {
+        const rtf::FlatNode& root = flat.nodes[0];
+        const float lo[3] = {root.minx, root.miny, root.minz}, hi[3] = {root.maxx, root.maxy, root.maxz};
+        for (int k = 0; k < 3; k++) s.extent[k] = std::fmax(std::fabs(lo[k]), std::fabs(hi[k]));
+    }
 
     rt_scene_info& inf = ctx->info;
     std::memset(&inf, 0, sizeof inf);
@@ -206,7 +262,8 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     inf.device_bytes = (int64_t)(flat.nodes.size() * 32 + (size_t)n_ts * 52 + (size_t)n_ss * 20 +
                                  (size_t)n_planes * 96 + (size_t)n_spheres * 48 + (size_t)n_triangles * 96 +
                                  (size_t)lights_len * 4);
-    inf.lds_scene_bytes = (int64_t)(flat.nodes.size() * 32 + (size_t)n_ts * 48 + (size_t)n_ss * 16);
+    inf.lds_scene_bytes = (int64_t)(geom_f4 * 16);
+    ctx->lds_capable = geom_f4 > 0 && geom_f4 * 16 <= (size_t)ctx->lds_limit;
     ctx->has_scene = true;
     return RT_OK;
 }
@@ -263,19 +320,37 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
     a.local_rows = rt_local_rows(h, band_rows, rank, world);
     a.band_rows = band_rows, a.rank = rank, a.world = world;
     a.tiles_x = (w + TILE - 1) / TILE;
-    a.n_tiles = a.tiles_x * ((a.local_rows + TILE - 1) / TILE);
+    a.tiles_y = (a.local_rows + TILE - 1) / TILE;
+    a.supertile = ctx->supertile;
+    // grid: whole super-tiles, their count padded to a multiple of the 8 XCD slots
+    const int n_super = ((a.tiles_x + a.supertile - 1) / a.supertile) * ((a.tiles_y + a.supertile - 1) / a.supertile);
+    const int n_blocks = ((n_super + 7) / 8) * 8 * a.supertile * a.supertile;
     a.rgb = d_rgb;
     a.rgba8 = (uint32_t*)d_rgba8;
     a.primary_id = d_primary_id;
     a.final_id = d_final_id;
     a.bounces = d_bounces;
     a.stats = (unsigned long long*)d_stats;
-    if (a.n_tiles == 0) return RT_OK;
+    a.ticket = nullptr;
+    a.ticket_base = 0;
+    if (a.tiles_y == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (!(flags & (RT_RENDER_REFERENCE_ORDER | RT_RENDER_GLOBAL_MEMORY)) && ctx->allow_lds && ctx->lds_capable) {
+        // LDS-resident persistent kernel: one workgroup per CU; each of its waves draws one ticket
+        // past the end, so the launch consumes exactly n_tiles + n_waves tickets
+        const unsigned int n_tiles8 = (unsigned int)(((w + 7) / 8) * ((a.local_rows + 7) / 8));
+        const int grid = (int)std::min<unsigned int>((unsigned int)ctx->n_cus, (n_tiles8 + 15) / 16);
+        a.ticket = (unsigned int*)ctx->ticket.p;
+        a.ticket_base = ctx->ticket_base;
+        ctx->ticket_base += n_tiles8 + (unsigned int)grid * (LDS_BLOCK / 64);
+        hipLaunchKernelGGL(k_render_lds, dim3(grid), dim3(LDS_BLOCK), (size_t)a.scene.geom_float4s * 16, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        return RT_OK;
+    }
     if (flags & RT_RENDER_REFERENCE_ORDER)
-        hipLaunchKernelGGL(k_render<true>, dim3(a.n_tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL(k_render<false>, dim3(a.n_tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_render<false>, dim3(n_blocks), dim3(256), 0, st, a);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }

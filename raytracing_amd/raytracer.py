@@ -71,6 +71,11 @@ class RayTracer:
         if rc != 0:
             raise RtError(rc, self._lib.rt_last_error(self._ctx).decode())
 
+    OPTION_USE_LDS, OPTION_SUPERTILE = 1, 2
+
+    def set_option(self, option, value):
+        self._check(self._lib.rt_set_option(self._ctx, int(option), int(value)))
+
     # ---- RayTracer.cs:957-1046 ------------------------------------------------------------
     def SendPrimitivesToShader(self, scene):
         """scene: raytracing_amd.host.Scene (or any object with the same six buffers)."""
