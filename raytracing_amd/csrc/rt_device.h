@@ -160,17 +160,36 @@ __device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4
     const float txf = ((r.sx ? lo.x : hi.x) - r.o.x) * r.inv.x;
     const float tyn = ((r.sy ? hi.y : lo.y) - r.o.y) * r.inv.y;
     const float tyf = ((r.sy ? lo.y : hi.y) - r.o.y) * r.inv.y;
-    if ((txn > tyf) || (tyn > txf)) return false;
+    // straight-line form of the reference's two early returns (same comparisons, same operands): in
+    // a wave-cooperative walk some lane nearly always takes the long path, so the exec-mask
+    // branches of the early returns only cost scalar instructions
+    const bool miss_xy = (txn > tyf) | (tyn > txf);
     const float mn = (tyn > txn) ? tyn : txn;
     const float mf = (tyf < txf) ? tyf : txf;
     const float tzn = ((r.sz ? hi.z : lo.z) - r.o.z) * r.inv.z;
     const float tzf = ((r.sz ? lo.z : hi.z) - r.o.z) * r.inv.z;
-    if ((mn > tzf) || (tzn > mf)) return false;
+    const bool miss_z = (mn > tzf) | (tzn > mf);
     // ---- not in the reference: padded-interval cull ----
     const float en = fmaxf(fmaxf(txn - r.padinv.x, tyn - r.padinv.y), tzn - r.padinv.z);
     const float ef = fminf(fminf(txf + r.padinv.x, tyf + r.padinv.y), tzf + r.padinv.z);
-    if ((en > t_hi) || (ef < t_lo)) return false;
-    return true;
+    const bool culled = (en > t_hi) | (ef < t_lo);
+    return !(miss_xy | miss_z | culled);
+}
+
+// IntersectTriangle for the fast kernels: same arithmetic, but the three edge tests are only
+// evaluated for lanes whose t already lies inside the caller's acceptance window (a t outside it
+// is rejected by the caller whatever the edge tests say), and the result is formed without
+// nested exec-mask branches.  window(t) must be the caller's own acceptance test.
+template <class Window>
+__device__ __forceinline__ float IntersectTriangleWindowed(V3 o, V3 d, V3 A, V3 B, V3 C, V3 N, Window&& window) {
+    const float den = dot(d, N);
+    const float t = dot(A - o, N) / den;  // den == 0 gives inf/NaN: masked out below (reference returns -1)
+    const bool candidate = (den != 0) & (t > 0) & window(t);
+    if (!candidate) return -1.0f;
+    const V3 X = o + t * d;
+    const bool outside = (dot(cross(B - A, X - A), N) < 0) | (dot(cross(C - B, X - B), N) < 0) |
+                         (dot(cross(A - C, X - C), N) < 0);
+    return outside ? -1.0f : t;
 }
 
 // ---- geometry fetch ----------------------------------------------------------------------

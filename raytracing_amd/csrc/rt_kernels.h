@@ -147,7 +147,14 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
         walk<true>(g, S.n_nodes, br, 2, false, cnt, sphere, tri);
     } else {
         planes();
-        wave_walk(g, S.n_nodes, br, true, minDistance, [&] { return h.t; }, sphere, tri, [] { return false; });
+        // edge tests only for a t the acceptance rule below could still take
+        auto tri_fast = [&](int slot) {
+            const TriG tg = load_tri(g, slot);
+            const float t = IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N,
+                                                      [&](float tt) { return closer(tt, 2, minDistance, h); });
+            if (closer(t, 2, minDistance, h)) h.t = t, h.kind = 2, h.index = slot;
+        };
+        wave_walk(g, S.n_nodes, br, true, minDistance, [&] { return h.t; }, sphere, tri_fast, [] { return false; });
     }
     return h;
 }
@@ -204,7 +211,7 @@ __device__ __forceinline__ bool object_in_way(const DevScene& S, const G& g, flo
         auto tri_any = [&](int slot) {
             if (blocked) return;
             const TriG tg = load_tri(g, slot);
-            if (in_range(IntersectTriangle(o, d, tg.A, tg.B, tg.C, tg.N))) blocked = true;
+            if (in_range(IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N, in_range))) blocked = true;
         };
         wave_walk(g, S.n_nodes, br, !blocked, RT_EPSILON, [&] { return distanceToLight; }, sphere, tri_any,
                   [&] { return blocked; });
@@ -360,16 +367,25 @@ __device__ __forceinline__ bool block_to_tile(int b, int st, int tiles_x, int ti
     return *tx < tiles_x && *ty < tiles_y;
 }
 
-constexpr int TILE = 16;  // 16x16 pixels per 256-thread workgroup, 8x8 per wave
+// Workgroup = RT_BLOCK_WAVES waves, each wave an 8x8 pixel tile.  No LDS and no barrier is used, so
+// the workgroup size only sets the scheduling granularity: one wave per workgroup lets the
+// dispatcher refill every freed wave slot on its own (measured against 4 waves: DESIGN.md).
+#ifndef RT_BLOCK_WAVES
+#define RT_BLOCK_WAVES 1
+#endif
+constexpr int BLOCK_WAVES = RT_BLOCK_WAVES;
+constexpr int TILE_X = BLOCK_WAVES >= 2 ? 16 : 8;  // pixels per workgroup tile
+constexpr int TILE_Y = BLOCK_WAVES >= 4 ? 16 : 8;
+static_assert(BLOCK_WAVES == 1 || BLOCK_WAVES == 2 || BLOCK_WAVES == 4, "1, 2 or 4 waves per workgroup");
 
 // ---- geometry in HBM/L2: one thread per pixel, one 16x16 tile per workgroup -------------------
 template <bool REF>
-__global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
+__global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a) {
     int tx, ty;
     const bool in_image = block_to_tile(blockIdx.x, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int r = ty * TILE + (wave >> 1) * 8 + (lane >> 3);  // local row
+    const int x = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
+    const int r = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);  // local row
     const int y = global_row(a, r);
     const bool live = in_image && x < a.width && r < a.local_rows && y < a.height;
     const GeomGlobal g{a.scene.geom, a.scene.tri_off, a.scene.sph_off};
@@ -379,10 +395,17 @@ __global__ __launch_bounds__(256) void k_render(const RenderArgs a) {
 #pragma unroll
         for (int k = 0; k < C_N; k++) cnt[k] = 0;
     }
+#ifdef RT_DIAG_WAVE_CYCLES  // diagnostic build only: the bounces plane receives each wave's lifetime in cycles
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
+#endif
     if (live) {
         const PixelOut p = shade_pixel<REF>(a.scene, g, a.cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, cnt);
         store_pixel(a, x, r, p);
     }
+#ifdef RT_DIAG_WAVE_CYCLES
+    if (!REF && live && a.bounces)
+        a.bounces[(size_t)r * a.width + x] = (int32_t)(__builtin_amdgcn_s_memtime() - diag_t0);
+#endif
     if (REF && a.stats) {
 #pragma unroll
         for (int k = 0; k < C_N; k++) {

@@ -27,7 +27,7 @@ struct rt_ctx {
     int device = 0;
     std::string error;
     bool has_scene = false;
-    int supertile = 4;  // tiles per super-tile edge (RT_SUPERTILE overrides; see block_to_tile)
+    int supertile = 8;  // workgroup tiles per super-tile edge: 8 x 8-pixel tiles = 64 px (block_to_tile)
     DevScene scene{};
     rt_scene_info info{};
     // scene buffers
@@ -319,8 +319,8 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
     a.width = w, a.height = h;
     a.local_rows = rt_local_rows(h, band_rows, rank, world);
     a.band_rows = band_rows, a.rank = rank, a.world = world;
-    a.tiles_x = (w + TILE - 1) / TILE;
-    a.tiles_y = (a.local_rows + TILE - 1) / TILE;
+    a.tiles_x = (w + TILE_X - 1) / TILE_X;
+    a.tiles_y = (a.local_rows + TILE_Y - 1) / TILE_Y;
     a.supertile = ctx->supertile;
     // grid: whole super-tiles, their count padded to a multiple of the 8 XCD slots
     const int n_super = ((a.tiles_x + a.supertile - 1) / a.supertile) * ((a.tiles_y + a.supertile - 1) / a.supertile);
@@ -348,9 +348,9 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
         return RT_OK;
     }
     if (flags & RT_RENDER_REFERENCE_ORDER)
-        hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
     else
-        hipLaunchKernelGGL(k_render<false>, dim3(n_blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_render<false>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
