@@ -76,8 +76,15 @@ enum {
     RT_OPTION_USE_LDS = 1,   /* 1: scenes whose flattened geometry fits the CU's 160 KB LDS are rendered by
                                 the LDS-resident persistent kernel; 0 (default): geometry stays in HBM/L2
                                 and is read through the scalar cache (measured faster) */
-    RT_OPTION_SUPERTILE = 2  /* edge, in 16x16-pixel tiles, of the super-tiles dealt round-robin to the
-                                XCDs by the global-memory kernel (default 4, 1..64) */
+    RT_OPTION_SUPERTILE = 2, /* edge, in 8x8-pixel tiles, of the super-tiles dealt round-robin to the
+                                XCDs by the global-memory kernels (default 8, 1..64) */
+    RT_OPTION_TRAVERSAL = 3  /* RT_TRAVERSAL_*: which fast kernel renders (default AUTO: by scene size) */
+};
+enum {
+    RT_TRAVERSAL_AUTO = 0,
+    RT_TRAVERSAL_WAVE = 1,   /* wave-cooperative stackless walk of the flattened tree (cache-resident scenes) */
+    RT_TRAVERSAL_BVH = 2     /* per-lane ordered traversal of the re-treed leaves, stacks in LDS; falls back
+                                to WAVE when the uploaded tree's boxes are not nested */
 };
 int rt_set_option(rt_ctx* ctx, int option, int value);
 
@@ -135,8 +142,15 @@ typedef struct rt_scene_info {
     int64_t max_depth;      /* deepest node of the R-tree                          */
     int64_t device_bytes;   /* bytes of HBM held by the scene                      */
     int64_t lds_scene_bytes;/* bytes the LDS-resident variant would need (0 = n/a) */
-    int64_t reserved[2];
+    int64_t bvh_nodes;      /* 64-byte nodes of the re-treed leaves (0 = not built)    */
+    int64_t bvh_levels;     /* LDS stack entries per lane the BVH kernel reserves      */
+    int64_t flags;          /* RT_SCENE_*                                              */
+    int64_t reserved[3];
 } rt_scene_info;
+enum {
+    RT_SCENE_NESTED = 1,    /* every box lies inside its parent's (true for every RTree.cs tree) */
+    RT_SCENE_CULL = 2       /* ... and every primitive inside its leaf box: distance culling is on */
+};
 int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out);
 
 /* Host-only validation + flatten dry run of an accel array: the same checks rt_upload_scene

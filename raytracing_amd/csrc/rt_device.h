@@ -35,6 +35,13 @@ struct DevScene {
     const float* lights;
     int32_t n_nodes, n_planes, n_spheres, n_tris, lights_len;
     float extent[3];  // per-axis max |coordinate| of the root box (scale of the distance-cull pad)
+    // distance-cull pad as a fraction of the coordinate scale: 2^-7, or +inf (= never cull) when the
+    // upload could not verify that every primitive lies inside its leaf box and every box inside its
+    // parent (hand-made accel arrays; the cull's proof needs both)
+    float cull_scale;
+    // re-treed leaves (rt_bvh.h): 4 x float4 per node, node 0 = root holder; null if not built
+    const float4* bvh;
+    int32_t bvh_levels;  // stack entries a traversal can need
 };
 
 struct GeomGlobal {
@@ -48,6 +55,28 @@ struct GeomGlobal {
 // dynamic LDS of the LDS-resident kernel; named directly (not through a generic pointer) so that
 // every access is a ds_read_b128, never a flat load
 extern __shared__ float4 rt_lds[];
+// geometry in HBM/L2 + the re-treed leaves, walked per lane with a stack in LDS (bvh_walk)
+struct GeomBvh {
+    const float4* base;
+    int tri_off, sph_off;
+    const float4* bvh;
+    int stack_base;  // dword index of this lane's stack inside the workgroup's LDS; entries 64 dwords apart
+#ifdef RT_DIAG_STEPS
+    int* diag;
+#endif
+    __device__ __forceinline__ float4 node_lo(int i) const { return base[2 * i]; }
+    __device__ __forceinline__ float4 node_hi(int i) const { return base[2 * i + 1]; }
+    __device__ __forceinline__ float4 tri(int slot, int k) const { return base[tri_off + 3 * slot + k]; }
+    __device__ __forceinline__ float4 sphere(int slot) const { return base[sph_off + slot]; }
+};
+template <class G>
+struct is_bvh {
+    static constexpr bool value = false;
+};
+template <>
+struct is_bvh<GeomBvh> {
+    static constexpr bool value = true;
+};
 struct GeomLds {
     int tri_off, sph_off;
     __device__ __forceinline__ float4 node_lo(int i) const { return rt_lds[2 * i]; }
@@ -119,11 +148,11 @@ __device__ __forceinline__ BoxRay make_box_ray(V3 o, V3 d) {
     r.padinv = v3(0, 0, 0);
     return r;
 }
-// extent = per-axis max |coordinate| of the root box (DevScene::extent)
-__device__ __forceinline__ BoxRay make_box_ray_cull(V3 o, V3 d, V3 extent) {
+// extent = per-axis max |coordinate| of the root box (DevScene::extent); scale = DevScene::cull_scale
+__device__ __forceinline__ BoxRay make_box_ray_cull(V3 o, V3 d, V3 extent, float scale) {
     BoxRay r = make_box_ray(o, d);
     const float E = fmaxf(fmaxf(fabsf(o.x) + extent.x, fabsf(o.y) + extent.y), fabsf(o.z) + extent.z);
-    const float pad = E * 0.0078125f;  // 2^-7 of the scale of every coordinate the ray can meet
+    const float pad = E * scale;  // 2^-7 of the scale of every coordinate the ray can meet
     r.padinv = v3(pad * fabsf(r.inv.x), pad * fabsf(r.inv.y), pad * fabsf(r.inv.z));
     return r;
 }
@@ -155,7 +184,7 @@ __device__ __forceinline__ bool IntersectBoundingBox(const BoxRay& r, float4 lo,
 // worst case is a grazing ray, discriminant ~ 0).  pad = E/128 = 7.8e-3*E covers both.  NaN slab
 // values (zero direction components) make every comparison false: no cull, as in the reference.
 __device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4 lo, float4 hi, float t_lo,
-                                                         float t_hi) {
+                                                         float t_hi, float* entry = nullptr) {
     const float txn = ((r.sx ? hi.x : lo.x) - r.o.x) * r.inv.x;
     const float txf = ((r.sx ? lo.x : hi.x) - r.o.x) * r.inv.x;
     const float tyn = ((r.sy ? hi.y : lo.y) - r.o.y) * r.inv.y;
@@ -173,6 +202,7 @@ __device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4
     const float en = fmaxf(fmaxf(txn - r.padinv.x, tyn - r.padinv.y), tzn - r.padinv.z);
     const float ef = fminf(fminf(txf + r.padinv.x, tyf + r.padinv.y), tzf + r.padinv.z);
     const bool culled = (en > t_hi) | (ef < t_lo);
+    if (entry) *entry = en;  // padded entry parameter: orders the two children of a BVH node
     return !(miss_xy | miss_z | culled);
 }
 
@@ -190,6 +220,13 @@ __device__ __forceinline__ float IntersectTriangleWindowed(V3 o, V3 d, V3 A, V3 
     const bool outside = (dot(cross(B - A, X - A), N) < 0) | (dot(cross(C - B, X - B), N) < 0) |
                          (dot(cross(A - C, X - C), N) < 0);
     return outside ? -1.0f : t;
+}
+
+// A ray whose origin and 1/d are finite: the precondition of the re-treed traversal (rt_bvh.h).
+__device__ __forceinline__ bool ray_is_regular(const BoxRay& r) {
+    const float big = 3.402823466e+38f;
+    return fabsf(r.inv.x) <= big && fabsf(r.inv.y) <= big && fabsf(r.inv.z) <= big && fabsf(r.o.x) <= 1e18f &&
+           fabsf(r.o.y) <= 1e18f && fabsf(r.o.z) <= 1e18f;
 }
 
 // ---- geometry fetch ----------------------------------------------------------------------
@@ -220,9 +257,11 @@ __device__ __forceinline__ Closest fresh_closest() { return Closest{RT_FLT_BIG, 
 // The shader tests all spheres, then all planes, then all triangles and accepts on strict
 // t < best; the winner is therefore the first candidate in (class, visit order) among those
 // of minimal t.  A streaming traversal meets classes interleaved, so equal t is resolved by
-// class rank; within a class the visit order is preserved and strict < keeps the first.
-__device__ __forceinline__ bool closer(float t, int kind, float minDistance, const Closest& h) {
-    return t > minDistance && (t < h.t || (t == h.t && kind < h.kind));
+// class rank, and within a class by slot (= position in the reference's visit order): an ordered
+// traversal meets the leaves in a ray-dependent order, and two intersecting triangles do produce
+// bit-identical t on the ray through their common line (seen on Soup1M at 4K).
+__device__ __forceinline__ bool closer(float t, int kind, int index, float minDistance, const Closest& h) {
+    return t > minDistance && (t < h.t || (t == h.t && (kind < h.kind || (kind == h.kind && index < h.index))));
 }
 
 // Material + normal of the winning hit (cold data, one fetch per query that hit something).

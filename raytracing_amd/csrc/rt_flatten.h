@@ -48,6 +48,10 @@ struct Flat {
     std::vector<int32_t> sphere_slot_id;  // slot -> sphere index (0..S-1)
     int64_t max_depth = 0;
     int64_t logical_nodes = 0;
+    // every node's box is finite and lies inside its parent's box, component by component (true for
+    // every tree RTree.cs builds: UpdateBoundingBox takes the exact min/max of the children,
+    // RTree.cs:332-377).  rt_bvh.h may re-tree the leaves only when this holds.
+    bool nested = true;
 };
 
 enum { FLATTEN_OK = 0, FLATTEN_MALFORMED = -2, FLATTEN_TOO_LARGE = -6 };
@@ -68,6 +72,7 @@ inline int flatten(const float* acc, int64_t len, int64_t n_spheres, int64_t n_t
     out->sphere_slot_id.clear();
     out->max_depth = 0;
     out->logical_nodes = 0;
+    out->nested = true;
     if (len == 0) return FLATTEN_OK;  // empty scene (RTree.cs:114-115): nothing to traverse
     if (len < 8 || acc == nullptr) {
         *err = "accel array shorter than one node header";
@@ -107,6 +112,16 @@ inline int flatten(const float* acc, int64_t len, int64_t n_spheres, int64_t n_t
         fn.maxx = n[3], fn.maxy = n[4], fn.maxz = n[5];
         fn.skip = 0;
         const int32_t me = (int32_t)out->nodes.size();
+        {
+            bool ok = true;
+            for (int k = 0; k < 6; k++) ok = ok && std::isfinite(n[k]) && std::fabs(n[k]) < 1e18f;
+            if (ok && p.parent >= 0) {
+                const FlatNode& up = out->nodes[p.parent];
+                ok = n[0] >= up.minx && n[1] >= up.miny && n[2] >= up.minz && n[3] <= up.maxx && n[4] <= up.maxy &&
+                     n[5] <= up.maxz;
+            }
+            if (!ok) out->nested = false;
+        }
         if (n[6] == 0.0f) {  // branch (raytracer_fs.glsl:180)
             if (count >= SLOT_LIMIT) return FLATTEN_TOO_LARGE;
             fn.meta = make_meta(false, KIND_BRANCH, 0, count);

@@ -102,18 +102,82 @@ __device__ __forceinline__ void wave_walk(const G& g, int n_nodes, const BoxRay&
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-lane ordered traversal of the re-treed leaves (rt_bvh.h), stack in LDS.
+//
+// Every lane walks its own ray: the two child boxes of a node are tested with the reference
+// formula (+ the distance cull), the nearer child (smaller padded entry parameter) is entered
+// first and the other is pushed.  The stack lives in LDS, one dword per level, entries of one lane
+// 64 dwords apart (lane-major rows: whatever the lanes' stack depths, lane l only ever touches bank
+// l % 64, so pushes and pops are conflict free).  "while-while" form: the wave first advances every
+// lane to its next leaf, then all lanes test their leaf's primitives together.
+// Only for regular rays of a nested tree (callers check); results do not depend on the visit
+// order because acceptance carries the explicit (class, slot) rank (closer()).
+// ------------------------------------------------------------------------------------------
+#ifdef RT_DIAG_STEPS  // diagnostic build only: per-lane step counters of bvh_walk (tools/diag_steps.py)
+#define rt_diag g.diag
+#endif
+template <class LeafSphere, class LeafTri, class Done, class THi>
+__device__ __forceinline__ void bvh_walk(const GeomBvh& g, const BoxRay& br, bool alive, float t_lo, THi&& t_hi,
+                                         LeafSphere&& on_sphere, LeafTri&& on_tri, Done&& done) {
+    constexpr uint32_t NONE = 0xFFFFFFFFu, LEAF = 0x80000000u;
+    uint32_t* const stk = (uint32_t*)rt_lds + g.stack_base;
+    int sp = 0;
+    uint32_t cur = alive ? 0u : NONE;
+    while (cur != NONE) {
+        while (!(cur & LEAF)) {
+#ifdef RT_DIAG_STEPS
+            rt_diag[0]++;
+            if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) rt_diag[2]++;
+#endif
+            const float4* nd = g.bvh + 4 * (size_t)cur;
+            const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            const float th = t_hi();
+            float e0, e1;
+            const bool h0 = IntersectBoundingBoxCull(br, q0, q1, t_lo, th, &e0);
+            const bool h1 = IntersectBoundingBoxCull(br, q2, q3, t_lo, th, &e1);
+            const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+            if (h0 & h1) {
+                const bool swap = e1 < e0;
+                stk[64 * sp++] = swap ? r0 : r1;
+                cur = swap ? r1 : r0;
+            } else if (h0 | h1) {
+                cur = h0 ? r0 : r1;
+            } else {
+                cur = sp ? stk[64 * --sp] : NONE;
+            }
+        }
+        if (cur != NONE) {
+            const int kind = (cur >> 29) & 3;
+            const int count = (cur >> 24) & 31;
+            const int first = cur & 0xFFFFFF;
+#ifdef RT_DIAG_STEPS
+            rt_diag[1] += count;
+            if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) rt_diag[3]++;
+#endif
+            if (kind == rtf::KIND_SPHERE) {
+                for (int k = 0; k < count; k++) on_sphere(first + k);
+            } else {
+                for (int k = 0; k < count; k++) on_tri(first + k);
+            }
+            cur = (!done() && sp) ? stk[64 * --sp] : NONE;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // FindClosestIntersection, raytracer_fs.glsl:241-297
 // ------------------------------------------------------------------------------------------
 template <bool REF, class G>
 __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V3 o, V3 d, float minDistance,
                                                 uint32_t* cnt) {
     Closest h = fresh_closest();
-    const BoxRay br = REF ? make_box_ray(o, d) : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]));
+    const BoxRay br = REF ? make_box_ray(o, d)
+                          : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
     auto sphere = [&](int slot) {
         const float4 s = g.sphere(slot);
         if (REF) cnt[C_SPHERE]++;
         const float4 r = IntersectSphere(o, d, v3(s.x, s.y, s.z), s.w);
-        if (closer(r.w, 0, minDistance, h)) {
+        if (closer(r.w, 0, slot, minDistance, h)) {
             if (REF) cnt[C_MAT]++;
             h.t = r.w, h.kind = 0, h.index = slot, h.n = v3(r.x, r.y, r.z);
         }
@@ -123,7 +187,7 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
         const TriG tg = load_tri(g, slot);
         if (REF) cnt[C_TRI]++;
         const float t = IntersectTriangle(o, d, tg.A, tg.B, tg.C, tg.N);
-        if (closer(t, 2, minDistance, h)) {
+        if (closer(t, 2, slot, minDistance, h)) {
             if (REF) cnt[C_MAT]++;
             h.t = t, h.kind = 2, h.index = slot;
         }
@@ -134,7 +198,7 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
             const float4 p = S.plane_geom[2 * k], nn = S.plane_geom[2 * k + 1];
             if (REF) cnt[C_PLANE]++;
             const float t = IntersectPlane(o, d, v3(p.x, p.y, p.z), v3(nn.x, nn.y, nn.z));
-            if (closer(t, 1, minDistance, h)) {
+            if (closer(t, 1, k, minDistance, h)) {
                 if (REF) cnt[C_MAT]++;
                 h.t = t, h.kind = 1, h.index = k;
             }
@@ -151,10 +215,23 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
         auto tri_fast = [&](int slot) {
             const TriG tg = load_tri(g, slot);
             const float t = IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N,
-                                                      [&](float tt) { return closer(tt, 2, minDistance, h); });
-            if (closer(t, 2, minDistance, h)) h.t = t, h.kind = 2, h.index = slot;
+                                                      [&](float tt) { return closer(tt, 2, slot, minDistance, h); });
+            if (closer(t, 2, slot, minDistance, h)) h.t = t, h.kind = 2, h.index = slot;
         };
-        wave_walk(g, S.n_nodes, br, true, minDistance, [&] { return h.t; }, sphere, tri_fast, [] { return false; });
+        if constexpr (is_bvh<G>::value) {
+            const bool regular = ray_is_regular(br);
+            if (!regular) {  // zero direction component etc.: the exact tree, exhaustively (rare)
+                auto tri_b = [&](int slot) {
+                    tri_fast(slot);
+                    return false;
+                };
+                walk<false>(g, S.n_nodes, br, 3, false, nullptr, sphere, tri_b);
+            }
+            bvh_walk(g, br, regular, minDistance, [&] { return h.t; }, sphere, tri_fast, [] { return false; });
+        } else {
+            wave_walk(g, S.n_nodes, br, true, minDistance, [&] { return h.t; }, sphere, tri_fast,
+                      [] { return false; });
+        }
     }
     return h;
 }
@@ -165,7 +242,8 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
 template <bool REF, class G>
 __device__ __forceinline__ bool object_in_way(const DevScene& S, const G& g, float distanceToLight, V3 o, V3 d,
                                               uint32_t* cnt) {
-    const BoxRay br = REF ? make_box_ray(o, d) : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]));
+    const BoxRay br = REF ? make_box_ray(o, d)
+                          : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
     bool blocked = false;
     auto in_range = [&](float t) { return t > RT_EPSILON && t < distanceToLight; };
     auto tri = [&](int slot) {
@@ -213,8 +291,25 @@ __device__ __forceinline__ bool object_in_way(const DevScene& S, const G& g, flo
             const TriG tg = load_tri(g, slot);
             if (in_range(IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N, in_range))) blocked = true;
         };
-        wave_walk(g, S.n_nodes, br, !blocked, RT_EPSILON, [&] { return distanceToLight; }, sphere, tri_any,
-                  [&] { return blocked; });
+        if constexpr (is_bvh<G>::value) {
+            const bool regular = ray_is_regular(br);
+            if (!regular && !blocked) {
+                auto sphere_b = [&](int slot) {
+                    sphere(slot);
+                    return blocked;
+                };
+                auto tri_b = [&](int slot) {
+                    tri_any(slot);
+                    return blocked;
+                };
+                walk<false>(g, S.n_nodes, br, 3, false, nullptr, sphere_b, tri_b);
+            }
+            bvh_walk(g, br, regular && !blocked, RT_EPSILON, [&] { return distanceToLight; }, sphere, tri_any,
+                     [&] { return blocked; });
+        } else {
+            wave_walk(g, S.n_nodes, br, !blocked, RT_EPSILON, [&] { return distanceToLight; }, sphere, tri_any,
+                      [&] { return blocked; });
+        }
         return blocked;
     }
 }
@@ -413,6 +508,37 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0 && v) atomicAdd(&a.stats[k], v);
         }
+    }
+}
+
+// ---- large scenes: per-lane ordered traversal of the re-treed leaves, stacks in LDS ----------------
+// Same pixel mapping as k_render; dynamic LDS = BLOCK_WAVES * 64 lanes * bvh_levels dwords.
+__global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render_bvh(const RenderArgs a) {
+    int tx, ty;
+    const bool in_image = block_to_tile(blockIdx.x, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
+    const int r = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);
+    const int y = global_row(a, r);
+    const bool live = in_image && x < a.width && r < a.local_rows && y < a.height;
+#ifdef RT_DIAG_STEPS
+    int diag[4] = {0, 0, 0, 0};
+    const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.bvh_levels + lane, diag};
+#else
+    const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.bvh_levels + lane};
+#endif
+    if (live) {
+        const PixelOut p =
+            shade_pixel<false>(a.scene, g, a.cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, nullptr);
+        store_pixel(a, x, r, p);
+#ifdef RT_DIAG_STEPS  // planes receive: bounces <- node steps, final_id <- primitive tests, primary_id <- wave
+                      // iterations (node << 16 | leaf) credited to the first active lane, rgb.x <- unused
+        const size_t i = (size_t)r * a.width + x;
+        if (a.bounces) a.bounces[i] = diag[0];
+        if (a.final_id) a.final_id[i] = diag[1];
+        if (a.primary_id) a.primary_id[i] = diag[2];
+        if (a.rgb) a.rgb[3 * i] = (float)diag[3];
+#endif
     }
 }
 

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_bvh.h"
 #include "rt_kernels.h"
 
 using namespace rtd;
@@ -31,7 +32,9 @@ struct rt_ctx {
     DevScene scene{};
     rt_scene_info info{};
     // scene buffers
-    DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights;
+    DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights, bvh;
+    int traversal = RT_TRAVERSAL_AUTO;  // RT_OPTION_TRAVERSAL
+    int bvh_min_nodes = 2048;           // auto: scenes with at least this many flat nodes take the BVH kernel
     // LDS-resident persistent kernel (k_render_lds)
     DevBuf ticket;
     unsigned int ticket_base = 0;
@@ -137,6 +140,10 @@ int rt_create(int device_id, rt_ctx** out) {
             ctx->lds_limit = std::min<int>(ctx->lds_limit, (int)prop.maxSharedMemoryPerMultiProcessor);
     }
     if (const char* v = getenv("RT_USE_LDS")) ctx->allow_lds = atoi(v) != 0;
+    if (const char* v = getenv("RT_TRAVERSAL")) {  // development override of RT_OPTION_TRAVERSAL
+        const int t = atoi(v);
+        if (t >= RT_TRAVERSAL_AUTO && t <= RT_TRAVERSAL_BVH) ctx->traversal = t;
+    }
     // the persistent kernel's ticket counter: zeroed once, never reset (rt_kernels.h)
     if (hipMalloc(&ctx->ticket.p, 256) != hipSuccess || hipMemset(ctx->ticket.p, 0, 256) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_render_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -154,6 +161,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    release(ctx->bvh);
     DevBuf* all[] = {&ctx->geom,       &ctx->plane_geom, &ctx->tri_slot_id, &ctx->sphere_slot_id, &ctx->spheres_aos,
                      &ctx->planes_aos, &ctx->tris_aos,   &ctx->lights,      &ctx->ticket,         &ctx->fb_rgb,
                      &ctx->fb_rgba8,   &ctx->fb_pid,     &ctx->fb_fid,      &ctx->fb_stats};
@@ -167,6 +175,11 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
     switch (option) {
         case RT_OPTION_USE_LDS:
             ctx->allow_lds = value != 0 && ctx->ticket.p != nullptr;
+            return RT_OK;
+        case RT_OPTION_TRAVERSAL:
+            if (value < RT_TRAVERSAL_AUTO || value > RT_TRAVERSAL_BVH)
+                return fail(ctx, RT_ERR_INVALID_ARGUMENT, "traversal must be 0 (auto), 1 (wave walk) or 2 (BVH)");
+            ctx->traversal = value;
             return RT_OK;
         case RT_OPTION_SUPERTILE:
             if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "supertile must be 1..64");
@@ -253,6 +266,50 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
         for (int k = 0; k < 3; k++) s.extent[k] = std::fmax(std::fabs(lo[k]), std::fabs(hi[k]));
     }
 
+    // distance cull precondition: boxes nested, every primitive inside its leaf box (within a slack
+    // far below the cull's pad); otherwise the kernels never cull
+    bool contained = flat.nested;
+    if (contained) {
+        const float slack = std::fmax(s.extent[0], std::fmax(s.extent[1], s.extent[2])) * (1.0f / 4096.0f);
+        const unsigned char* T = (const unsigned char*)triangles;
+        const unsigned char* Sp = (const unsigned char*)spheres;
+        for (const rtf::FlatNode& fn : flat.nodes) {
+            const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = fn.meta & 0xFFFFFF;
+            if (kind == rtf::KIND_BRANCH) continue;
+            const float lo[3] = {fn.minx - slack, fn.miny - slack, fn.minz - slack};
+            const float hi[3] = {fn.maxx + slack, fn.maxy + slack, fn.maxz + slack};
+            for (int k = 0; k < count && contained; k++) {
+                if (kind == rtf::KIND_TRI) {
+                    const float* rec = (const float*)(T + (size_t)flat.tri_slot_id[first + k] * 96);
+                    for (int v = 0; v < 3; v++)
+                        for (int c = 0; c < 3; c++) {
+                            const float x = rec[4 * v + c];
+                            if (!(x >= lo[c] && x <= hi[c])) contained = false;
+                        }
+                } else {
+                    const float* rec = (const float*)(Sp + (size_t)flat.sphere_slot_id[first + k] * 48);
+                    for (int c = 0; c < 3; c++)
+                        if (!(rec[c] - rec[3] >= lo[c] && rec[c] + rec[3] <= hi[c]) || !(rec[3] >= 0)) contained = false;
+                }
+            }
+            if (!contained) break;
+        }
+    }
+    s.cull_scale = contained ? 0.0078125f : INFINITY;
+
+    // re-treed leaves for the per-lane kernel (only for nested trees, rt_bvh.h)
+    s.bvh = nullptr;
+    s.bvh_levels = 0;
+    rtb::Bvh bvh;
+    if (flat.nested) {
+        rtb::build(flat, &bvh);
+        if (!bvh.nodes.empty()) {
+            if ((rc = upload(ctx, ctx->bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtb::Node)))) return rc;
+            s.bvh = (const float4*)ctx->bvh.p;
+            s.bvh_levels = bvh.levels;
+        }
+    }
+
     rt_scene_info& inf = ctx->info;
     std::memset(&inf, 0, sizeof inf);
     inf.n_nodes = (int64_t)flat.nodes.size();
@@ -263,6 +320,10 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
                                  (size_t)n_planes * 96 + (size_t)n_spheres * 48 + (size_t)n_triangles * 96 +
                                  (size_t)lights_len * 4);
     inf.lds_scene_bytes = (int64_t)(geom_f4 * 16);
+    inf.bvh_nodes = (int64_t)bvh.nodes.size();
+    inf.bvh_levels = bvh.levels;
+    inf.flags = (flat.nested ? RT_SCENE_NESTED : 0) | (contained ? RT_SCENE_CULL : 0);
+    inf.device_bytes += (int64_t)(bvh.nodes.size() * sizeof(rtb::Node));
     ctx->lds_capable = geom_f4 > 0 && geom_f4 * 16 <= (size_t)ctx->lds_limit;
     ctx->has_scene = true;
     return RT_OK;
@@ -288,6 +349,13 @@ int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_t
         info->max_depth = flat.max_depth;
         info->lds_scene_bytes =
             (int64_t)(flat.nodes.size() * 32 + flat.tri_slot_id.size() * 48 + flat.sphere_slot_id.size() * 16);
+        info->flags = flat.nested ? RT_SCENE_NESTED : 0;  // RT_SCENE_CULL needs the primitives: upload only
+        if (flat.nested) {
+            rtb::Bvh bvh;
+            rtb::build(flat, &bvh);
+            info->bvh_nodes = (int64_t)bvh.nodes.size();
+            info->bvh_levels = bvh.levels;
+        }
     }
     return rc;
 }
@@ -347,8 +415,14 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
         HIP_TRY(ctx, hipGetLastError());
         return RT_OK;
     }
+    const bool bvh_ok = a.scene.bvh != nullptr && a.scene.bvh_levels <= rtb::MAX_LEVELS;
+    const bool use_bvh = bvh_ok && (ctx->traversal == RT_TRAVERSAL_BVH ||
+                                    (ctx->traversal == RT_TRAVERSAL_AUTO && a.scene.n_nodes >= ctx->bvh_min_nodes));
     if (flags & RT_RENDER_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
+    else if (use_bvh)
+        hipLaunchKernelGGL(k_render_bvh, dim3(n_blocks), dim3(64 * BLOCK_WAVES),
+                           (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4, st, a);
     else
         hipLaunchKernelGGL(k_render<false>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
     HIP_TRY(ctx, hipGetLastError());
