@@ -83,8 +83,11 @@ enum {
 enum {
     RT_TRAVERSAL_AUTO = 0,
     RT_TRAVERSAL_WAVE = 1,   /* wave-cooperative stackless walk of the flattened tree (cache-resident scenes) */
-    RT_TRAVERSAL_BVH = 2     /* per-lane ordered traversal of the re-treed leaves, stacks in LDS; falls back
+    RT_TRAVERSAL_BVH = 2,    /* per-lane ordered traversal of the re-treed leaves, stacks in LDS; falls back
                                 to WAVE when the uploaded tree's boxes are not nested */
+    RT_TRAVERSAL_WAVEFRONT = 3 /* the same traversal, staged: per bounce a closest-hit, a shadow and a shading
+                                stage over ray queues, idle lanes refilled by ballot compaction (large
+                                scenes); falls back like BVH, and to BVH when max_bounces > 64 */
 };
 int rt_set_option(rt_ctx* ctx, int option, int value);
 

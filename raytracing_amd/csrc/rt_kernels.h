@@ -330,16 +330,73 @@ __device__ __forceinline__ Surface no_surface() {
     return sf;
 }
 
-template <bool REF, class G>
-__device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, const float* cam, float px, float py,
-                                                int maxBounces, uint32_t* cnt) {
+// one light of the scene as seen from a shaded point (raytracer_fs.glsl:344-348, 402-406)
+struct LightRay {
+    V3 L, colour;
+    float dist;
+};
+__device__ __forceinline__ LightRay light_ray(const DevScene& S, int l, V3 hitPos) {
+    const float* q = S.lights + 6 * l;
+    const V3 lightPos = v3(q[0], q[1], q[2]);
+    LightRay r;
+    r.dist = length(lightPos - hitPos);
+    r.L = normalize(lightPos - hitPos);
+    r.colour = v3(q[3], q[4], q[5]);
+    return r;
+}
+// raytracer_fs.glsl:342-357: a mirror with a diffuse component (the normal is not flipped here).
+// in_shadow(l, lightRay) is the caller's ObjectInWayOfLight (traced inline, or read back from the
+// any-hit stage of the wavefront pipeline).
+template <class Shadow>
+__device__ __forceinline__ V3 mirror_diffuse_term(const DevScene& S, const Surface& sf, V3 hitPos, Shadow&& in_shadow) {
+    V3 combined = sf.diffuse * v3(0.1f, 0.1f, 0.1f);
+    for (int l = 0; l < S.lights_len / 6; l++) {
+        const LightRay lr = light_ray(S, l, hitPos);
+        if (!in_shadow(l, lr))
+            combined = combined + 1.0f / (lr.dist * lr.dist) * lr.colour * sf.diffuse * max0(dot(sf.normal, lr.L));
+    }
+    return combined;
+}
+// raytracer_fs.glsl:361-366: the reflected ray
+__device__ __forceinline__ V3 mirror_direction(const Surface& sf, V3 rayDirection) {
+    V3 n = sf.normal;
+    if (dot(n, rayDirection) > 0.0f) n = -n;
+    return normalize(rayDirection - 2 * dot(rayDirection, n) * n);
+}
+// raytracer_fs.glsl:398-424 (a hit that is still pure specular at the bounce cap is shaded too)
+template <class Shadow>
+__device__ __forceinline__ V3 phong_term(const DevScene& S, const Surface& sf, V3 hitPos, V3 rayDirection,
+                                         Shadow&& in_shadow) {
+    V3 combined = sf.diffuse * v3(0.1f, 0.1f, 0.1f);
+    V3 n = sf.normal;
+    for (int l = 0; l < S.lights_len / 6; l++) {
+        const LightRay lr = light_ray(S, l, hitPos);
+        if (!in_shadow(l, lr)) {
+            if (dot(n, rayDirection) > 0.0f) n = -n;
+            const V3 R = normalize(lr.L - 2 * dot(lr.L, n) * n);
+            combined = combined + 1.0f / (lr.dist * lr.dist) * lr.colour *
+                                      (sf.diffuse * max0(dot(n, lr.L)) +
+                                       sf.specular * powf(max0(dot(rayDirection, R)), sf.specularity));
+        }
+    }
+    return combined;
+}
+// raytracer_fs.glsl:302-313
+__device__ __forceinline__ V3 primary_direction(const float* cam, float px, float py) {
     const float width = cam[12], height = cam[13];
     const V3 bottomLeft = v3(cam[3], cam[4], cam[5]);
     const V3 bottomRight = v3(cam[6], cam[7], cam[8]);
     const V3 topLeft = v3(cam[9], cam[10], cam[11]);
+    const V3 rayOrigin = v3(cam[0], cam[1], cam[2]);
+    return normalize((bottomLeft + (px / width) * (bottomRight - bottomLeft) + (py / height) * (topLeft - bottomLeft)) -
+                     rayOrigin);
+}
+
+template <bool REF, class G>
+__device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, const float* cam, float px, float py,
+                                                int maxBounces, uint32_t* cnt) {
     V3 rayOrigin = v3(cam[0], cam[1], cam[2]);
-    V3 rayDirection = normalize(
-        (bottomLeft + (px / width) * (bottomRight - bottomLeft) + (py / height) * (topLeft - bottomLeft)) - rayOrigin);
+    V3 rayDirection = primary_direction(cam, px, py);
 
     if (REF) cnt[C_PRIMARY]++;
     Closest h = find_closest<REF>(S, g, rayOrigin, rayDirection, 0.0f, cnt);
@@ -354,23 +411,13 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
         if (REF) cnt[C_SECONDARY]++;
         const V3 hitPos = rayOrigin + h.t * rayDirection;
         if (sf.diffuse.x != 0 || sf.diffuse.y != 0 || sf.diffuse.z != 0) {
-            // raytracer_fs.glsl:342-357 (mirror with a diffuse component; the normal is not flipped here)
-            V3 combined = sf.diffuse * v3(0.1f, 0.1f, 0.1f);
-            for (int l = 0; l < S.lights_len; l += 6) {
-                const V3 lightPos = v3(S.lights[l], S.lights[l + 1], S.lights[l + 2]);
-                const float dist = length(lightPos - hitPos);
-                const V3 L = normalize(lightPos - hitPos);
-                if (!object_in_way<REF>(S, g, dist, hitPos, L, cnt)) {
-                    const V3 lightColor = v3(S.lights[l + 3], S.lights[l + 4], S.lights[l + 5]);
-                    combined = combined + 1.0f / (dist * dist) * lightColor * sf.diffuse * max0(dot(sf.normal, L));
-                }
-            }
+            const V3 combined = mirror_diffuse_term(S, sf, hitPos, [&](int, const LightRay& lr) {
+                return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt);
+            });
             finalColor = finalColor + combined * mult;
         }
         mult = mult * sf.specular;
-        V3 n = sf.normal;
-        if (dot(n, rayDirection) > 0.0f) n = -n;
-        const V3 refl = normalize(rayDirection - 2 * dot(rayDirection, n) * n);
+        const V3 refl = mirror_direction(sf, rayDirection);
         rayOrigin = hitPos;
         rayDirection = refl;
         h = find_closest<REF>(S, g, rayOrigin, rayDirection, RT_EPSILON, cnt);
@@ -383,23 +430,10 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
         out.rgb = finalColor + v3(0.5f, 0.6f, 1.0f) * mult;
         return out;
     }
-    // raytracer_fs.glsl:398-424 (a hit that is still pure specular at the bounce cap is shaded too)
     const V3 hitPos = rayOrigin + h.t * rayDirection;
-    V3 combined = sf.diffuse * v3(0.1f, 0.1f, 0.1f);
-    V3 n = sf.normal;
-    for (int l = 0; l < S.lights_len; l += 6) {
-        const V3 lightPos = v3(S.lights[l], S.lights[l + 1], S.lights[l + 2]);
-        const float dist = length(lightPos - hitPos);
-        const V3 L = normalize(lightPos - hitPos);
-        if (!object_in_way<REF>(S, g, dist, hitPos, L, cnt)) {
-            const V3 lightColor = v3(S.lights[l + 3], S.lights[l + 4], S.lights[l + 5]);
-            if (dot(n, rayDirection) > 0.0f) n = -n;
-            const V3 R = normalize(L - 2 * dot(L, n) * n);
-            combined = combined + 1.0f / (dist * dist) * lightColor *
-                                      (sf.diffuse * max0(dot(n, L)) +
-                                       sf.specular * powf(max0(dot(rayDirection, R)), sf.specularity));
-        }
-    }
+    const V3 combined = phong_term(S, sf, hitPos, rayDirection, [&](int, const LightRay& lr) {
+        return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt);
+    });
     out.rgb = finalColor + combined * mult;
     return out;
 }

@@ -12,6 +12,7 @@
 
 #include "rt_bvh.h"
 #include "rt_kernels.h"
+#include "rt_wavefront.h"
 
 using namespace rtd;
 
@@ -34,7 +35,8 @@ struct rt_ctx {
     // scene buffers
     DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights, bvh;
     int traversal = RT_TRAVERSAL_AUTO;  // RT_OPTION_TRAVERSAL
-    int bvh_min_nodes = 2048;           // auto: scenes with at least this many flat nodes take the BVH kernel
+    int bvh_min_nodes = 0;              // auto: scenes with at least this many flat nodes take the BVH kernel
+                                        // (measured faster than the wave walk on every scene)
     // LDS-resident persistent kernel (k_render_lds)
     DevBuf ticket;
     unsigned int ticket_base = 0;
@@ -42,6 +44,11 @@ struct rt_ctx {
     bool lds_capable = false;   // the scene's geometry image fits the CU's LDS
     int lds_limit = 160 * 1024;  // bytes of dynamic LDS one workgroup may take (160 KB per CU)
     bool allow_lds = false;     // opt-in (RT_OPTION_USE_LDS): measured slower than the scalar-load walk
+    // path state of the wavefront pipeline (rt_wavefront.h; grow only)
+    DevBuf wf_org, wf_dir, wf_mult, wf_final, wf_list0, wf_list1, wf_blocked, wf_counters;
+    int wf_min_nodes = 100000; // auto: scenes with at least this many flat nodes take the wavefront pipeline
+    int wf_max_bounces = 64;   // beyond this the per-bounce launches stop paying: megakernel instead
+    int wf_waves_per_cu = 24;  // persistent waves of the two trace stages
     // frame buffers of rt_render (grow only)
     DevBuf fb_rgb, fb_rgba8, fb_pid, fb_fid, fb_stats;
     // scratch of the evaluators
@@ -88,6 +95,8 @@ void release(DevBuf& b) {
     b.bytes = 0;
 }
 
+bool r_max_ok(const rt_ctx* ctx, int max_bounces) { return max_bounces <= ctx->wf_max_bounces; }
+
 int camera_size(const float* cam, int* w, int* h) {
     if (!cam) return RT_ERR_INVALID_ARGUMENT;
     const float fw = cam[12], fh = cam[13];
@@ -95,6 +104,54 @@ int camera_size(const float* cam, int* w, int* h) {
     if (fw != (float)(int)fw || fh != (float)(int)fh) return RT_ERR_INVALID_ARGUMENT;
     *w = (int)fw;
     *h = (int)fh;
+    return RT_OK;
+}
+
+// The staged pipeline of rt_wavefront.h: per bounce one closest-hit stage, one shadow stage, one
+// shading stage, all on `st`; list sizes stay on the device (persistent / grid-stride kernels read
+// them), so the host never synchronises.
+int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st) {
+    WfArgs a;
+    a.scene = r.scene;
+    std::memcpy(a.cam, r.cam, sizeof a.cam);
+    a.max_bounces = r.max_bounces;
+    a.width = r.width, a.height = r.height, a.local_rows = r.local_rows;
+    a.band_rows = r.band_rows, a.rank = r.rank, a.world = r.world;
+    a.tiles_x = (r.width + 7) / 8, a.tiles_y = (r.local_rows + 7) / 8;
+    a.n_lights = r.scene.lights_len / 6;
+    a.iter = 0;
+    const size_t n0 = (size_t)a.tiles_x * a.tiles_y * 64;
+    if (n0 * (size_t)std::max(a.n_lights, 1) >= 0xFFFFFFF0ull)
+        return fail(ctx, RT_ERR_TOO_LARGE, "frame x lights exceeds the 32-bit work index of the wavefront pipeline");
+    a.n0 = (uint32_t)n0;
+    a.rgb = r.rgb, a.rgba8 = r.rgba8, a.primary_id = r.primary_id, a.final_id = r.final_id, a.bounces = r.bounces;
+    const size_t n_px = (size_t)r.width * r.local_rows;
+    const size_t n_counters = 4 * ((size_t)r.max_bounces + 2);
+    int rc;
+    if ((rc = ensure(ctx, ctx->wf_org, n_px * 16)) || (rc = ensure(ctx, ctx->wf_dir, n_px * 16)) ||
+        (rc = ensure(ctx, ctx->wf_mult, n_px * 16)) || (rc = ensure(ctx, ctx->wf_final, n_px * 16)) ||
+        (rc = ensure(ctx, ctx->wf_list0, n_px * 4)) || (rc = ensure(ctx, ctx->wf_list1, n_px * 4)) ||
+        (rc = ensure(ctx, ctx->wf_blocked, n0 * (size_t)std::max(a.n_lights, 1))) ||
+        (rc = ensure(ctx, ctx->wf_counters, n_counters * 4)))
+        return rc;
+    a.org_t = (float4*)ctx->wf_org.p, a.dir_hit = (float4*)ctx->wf_dir.p;
+    a.mult_b = (float4*)ctx->wf_mult.p, a.final_ = (float4*)ctx->wf_final.p;
+    a.list[0] = (uint32_t*)ctx->wf_list0.p, a.list[1] = (uint32_t*)ctx->wf_list1.p;
+    a.blocked = (unsigned char*)ctx->wf_blocked.p;
+    a.counters = (uint32_t*)ctx->wf_counters.p;
+    HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, n_counters * 4, st));
+    const int trace_grid = ctx->n_cus * ctx->wf_waves_per_cu;
+    const size_t lds = (size_t)64 * std::max(a.scene.bvh_levels, 1) * 4;
+    const int shade_grid = ctx->n_cus * 8;
+    for (int i = 0; i <= r.max_bounces; i++) {
+        a.iter = i;
+        // iteration 0 knows its size; later lists are at most as long as the frame
+        const int g0 = (int)std::min<size_t>((size_t)trace_grid, (n0 + 63) / 64);
+        hipLaunchKernelGGL(k_wf_closest, dim3(i == 0 ? g0 : trace_grid), dim3(64), lds, st, a);
+        if (a.n_lights > 0) hipLaunchKernelGGL(k_wf_any, dim3(trace_grid), dim3(64), lds, st, a);
+        hipLaunchKernelGGL(k_wf_shade, dim3(shade_grid), dim3(256), 0, st, a);
+    }
+    HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
 
@@ -142,7 +199,7 @@ int rt_create(int device_id, rt_ctx** out) {
     if (const char* v = getenv("RT_USE_LDS")) ctx->allow_lds = atoi(v) != 0;
     if (const char* v = getenv("RT_TRAVERSAL")) {  // development override of RT_OPTION_TRAVERSAL
         const int t = atoi(v);
-        if (t >= RT_TRAVERSAL_AUTO && t <= RT_TRAVERSAL_BVH) ctx->traversal = t;
+        if (t >= RT_TRAVERSAL_AUTO && t <= RT_TRAVERSAL_WAVEFRONT) ctx->traversal = t;
     }
     // the persistent kernel's ticket counter: zeroed once, never reset (rt_kernels.h)
     if (hipMalloc(&ctx->ticket.p, 256) != hipSuccess || hipMemset(ctx->ticket.p, 0, 256) != hipSuccess ||
@@ -162,6 +219,9 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     release(ctx->bvh);
+    DevBuf* wf[] = {&ctx->wf_org,   &ctx->wf_dir,   &ctx->wf_mult,    &ctx->wf_final,
+                    &ctx->wf_list0, &ctx->wf_list1, &ctx->wf_blocked, &ctx->wf_counters};
+    for (DevBuf* b : wf) release(*b);
     DevBuf* all[] = {&ctx->geom,       &ctx->plane_geom, &ctx->tri_slot_id, &ctx->sphere_slot_id, &ctx->spheres_aos,
                      &ctx->planes_aos, &ctx->tris_aos,   &ctx->lights,      &ctx->ticket,         &ctx->fb_rgb,
                      &ctx->fb_rgba8,   &ctx->fb_pid,     &ctx->fb_fid,      &ctx->fb_stats};
@@ -177,8 +237,8 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
             ctx->allow_lds = value != 0 && ctx->ticket.p != nullptr;
             return RT_OK;
         case RT_OPTION_TRAVERSAL:
-            if (value < RT_TRAVERSAL_AUTO || value > RT_TRAVERSAL_BVH)
-                return fail(ctx, RT_ERR_INVALID_ARGUMENT, "traversal must be 0 (auto), 1 (wave walk) or 2 (BVH)");
+            if (value < RT_TRAVERSAL_AUTO || value > RT_TRAVERSAL_WAVEFRONT)
+                return fail(ctx, RT_ERR_INVALID_ARGUMENT, "traversal must be one of RT_TRAVERSAL_*");
             ctx->traversal = value;
             return RT_OK;
         case RT_OPTION_SUPERTILE:
@@ -418,8 +478,13 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
     const bool bvh_ok = a.scene.bvh != nullptr && a.scene.bvh_levels <= rtb::MAX_LEVELS;
     const bool use_bvh = bvh_ok && (ctx->traversal == RT_TRAVERSAL_BVH ||
                                     (ctx->traversal == RT_TRAVERSAL_AUTO && a.scene.n_nodes >= ctx->bvh_min_nodes));
+    const bool use_wf = bvh_ok && r_max_ok(ctx, max_bounces) &&
+                        (ctx->traversal == RT_TRAVERSAL_WAVEFRONT ||
+                         (ctx->traversal == RT_TRAVERSAL_AUTO && a.scene.n_nodes >= ctx->wf_min_nodes));
     if (flags & RT_RENDER_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
+    else if (use_wf)
+        return launch_wavefront(ctx, a, st);
     else if (use_bvh)
         hipLaunchKernelGGL(k_render_bvh, dim3(n_blocks), dim3(64 * BLOCK_WAVES),
                            (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4, st, a);

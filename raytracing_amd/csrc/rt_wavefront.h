@@ -1,0 +1,419 @@
+// rt_wavefront.h -- the staged ("wavefront") form of the per-pixel path for large scenes.
+//
+// A megakernel keeps one pixel per lane from the primary ray to the last shadow ray.  On a scene whose
+// rays need very different numbers of traversal steps (Soup1M: mean 135 node steps, heavy tail) a wave
+// then runs at the pace of its slowest lane: measured lane utilisation of the traversal loop 9 %
+// (tools/diag_steps.py).  Here the path is cut at every ray, and the rays of ALL pixels are regrouped:
+//
+//   for iteration i = 0 .. max_bounces            (i = number of mirror bounces already taken)
+//     k_wf_closest  persistent waves; every lane draws the next ray of the active list when its own
+//                   ray is finished (ballot + mbcnt compaction of the idle lanes, one atomic per
+//                   refill), so the traversal loop always runs with >= 56 of 64 lanes busy
+//     k_wf_any      the same for the shadow rays: work item (active path j, light l)
+//     k_wf_shade    one thread per active path: the reference's shading code for this bounce
+//                   (raytracer_fs.glsl:334-381 or 384-424), appends mirror paths to the next list
+//
+// Per-path state lives in HBM as four float4 planes indexed by the local pixel; what a stage does not
+// change it does not touch.  The arithmetic of every stage is the megakernel's (same helpers, same
+// order of operations per pixel, lights summed in index order), so results are identical.
+#pragma once
+#include "rt_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace rtd {
+
+struct WfArgs {
+    DevScene scene;
+    float cam[14];
+    int max_bounces;
+    int width, height, local_rows, band_rows, rank, world;
+    int tiles_x, tiles_y;  // 8x8-pixel tiles of the local frame: iteration 0 walks pixels in tile order
+    int n_lights;
+    int iter;
+    uint32_t n0;  // work items of iteration 0 = tiles * 64
+    float* rgb;
+    uint32_t* rgba8;
+    int32_t* primary_id;
+    int32_t* final_id;
+    int32_t* bounces;
+    float4* org_t;    // ray origin.xyz | t of the closest hit (RT_FLT_BIG = miss)
+    float4* dir_hit;  // ray direction.xyz | packed hit (kind << 28 | slot or plane index)
+    float4* mult_b;   // mult.xyz | -
+    float4* final_;   // finalColor.xyz | -
+    uint32_t* list[2];       // active pixels of odd / even iterations >= 1
+    unsigned char* blocked;  // [active index j * n_lights + l]: shadow ray result of this iteration
+    uint32_t* counters;      // per iteration i: [4i] active paths, [4i+1] closest fetch head, [4i+2] any-hit fetch head
+};
+
+constexpr uint32_t WF_NO_HIT = 3u << 28;
+__device__ __forceinline__ uint32_t wf_pack_hit(int kind, int index) { return ((uint32_t)kind << 28) | (uint32_t)(index & 0xFFFFFF); }
+
+// work item k of iteration 0 -> local pixel index, or -1 outside the image (ragged right/top tiles)
+__device__ __forceinline__ int wf_pixel_of(const WfArgs& a, uint32_t k, int* x_out, int* r_out) {
+    const int tile = (int)(k >> 6), in = (int)(k & 63);
+    const int x = (tile % a.tiles_x) * 8 + (in & 7);
+    const int r = (tile / a.tiles_x) * 8 + (in >> 3);
+    *x_out = x, *r_out = r;
+    if (x >= a.width || r >= a.local_rows) return -1;
+    return r * a.width + x;
+}
+__device__ __forceinline__ int wf_global_row(const WfArgs& a, int r) {
+    return ((r / a.band_rows) * a.world + a.rank) * a.band_rows + r % a.band_rows;
+}
+// (selected without indexing the by-value argument struct, which would force a copy of it to scratch)
+__device__ __forceinline__ const uint32_t* wf_list_in(const WfArgs& a) { return (a.iter & 1) ? a.list[1] : a.list[0]; }
+__device__ __forceinline__ uint32_t* wf_list_out(const WfArgs& a) { return (a.iter & 1) ? a.list[0] : a.list[1]; }
+__device__ __forceinline__ uint32_t wf_active_count(const WfArgs& a) { return a.iter == 0 ? a.n0 : a.counters[4 * a.iter]; }
+
+constexpr int WF_REFILL = 8;  // idle lanes that trigger a refill (wave runs >= 56/64 busy until the list ends)
+
+// Draw work items for the idle lanes of the wave: one atomic per call.  Returns this lane's item or
+// 0xFFFFFFFF; *exhausted becomes true (wave-uniform) once the list has been handed out completely.
+__device__ __forceinline__ uint32_t wf_draw(uint32_t* head, uint32_t total, bool idle, bool* exhausted) {
+    const unsigned long long mask = __ballot(idle);
+    const int n_idle = __popcll(mask);
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll(mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(head, (uint32_t)n_idle);
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (base + (uint32_t)n_idle >= total || base >= total) *exhausted = true;
+    const uint32_t k = base + (uint32_t)rank;
+    return (idle && k < total) ? k : 0xFFFFFFFFu;
+}
+
+// ------------------------------------------------------------------------------------------
+// The persistent, vote-scheduled traversal loop shared by the two trace stages.
+//
+// Every lane owns one ray (cur = its current node or leaf, lk = next primitive of the leaf, stack in
+// LDS).  Rays of one wave are at unrelated points of their walks, so instead of letting the wave run
+// "all node steps, then all leaves" (lanes that reached a leaf wait for the longest node chain:
+// measured 25 % lane utilisation) each trip of the loop takes a vote: if at least as many lanes
+// stand at an inner node as at a leaf the wave executes ONE node step, otherwise ONE primitive
+// test.  The executed step is therefore always wanted by >= half of the busy lanes, the others wait
+// one trip.  A lane whose ray ends writes its result and turns idle; once WF_REFILL lanes are idle
+// they draw new rays (wf_draw).  Job supplies the ray: setup(k) -> bool (needs a traversal),
+// t_lo, t_hi(), sphere(slot), tri(slot), done(), finish().
+// ------------------------------------------------------------------------------------------
+template <class Job>
+__device__ __forceinline__ void wf_run(const GeomBvh& g, uint32_t* head, uint32_t total, Job& job) {
+    constexpr uint32_t NONE = 0xFFFFFFFFu, LEAF = 0x80000000u;
+    uint32_t* const stk = (uint32_t*)rt_lds + g.stack_base;
+    bool exhausted = false;
+    uint32_t cur = NONE;
+    int sp = 0, lk = 0;
+    for (;;) {
+        const unsigned long long idle_m = __ballot(cur == NONE);
+        const int n_idle = __popcll(idle_m);
+        if (!exhausted && n_idle >= WF_REFILL) {
+            const uint32_t k = wf_draw(head, total, cur == NONE, &exhausted);
+            if (k != NONE && job.setup(k)) cur = 0u, sp = 0, lk = 0;
+            continue;
+        }
+        if (n_idle == 64) {
+            if (exhausted) break;
+            continue;
+        }
+        const bool at_leaf = cur != NONE && (cur & LEAF);
+        const int n_leaf = __popcll(__ballot(at_leaf));
+        if (64 - n_idle - n_leaf >= n_leaf) {
+            if (!(cur & LEAF)) {  // node step (NONE has the leaf bit)
+                const float4* nd = g.bvh + 4 * (size_t)cur;
+                const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+                const float th = job.t_hi();
+                float e0, e1;
+                const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+                const bool h0 = IntersectBoundingBoxCull(job.br, q0, q1, job.t_lo, th, &e0) & (r0 != LEAF);
+                const bool h1 = IntersectBoundingBoxCull(job.br, q2, q3, job.t_lo, th, &e1) & (r1 != LEAF);
+                if (h0 & h1) {
+                    const bool swap = e1 < e0;
+                    stk[64 * sp++] = swap ? r0 : r1;
+                    cur = swap ? r1 : r0;
+                } else if (h0 | h1) {
+                    cur = h0 ? r0 : r1;
+                } else if (sp) {
+                    cur = stk[64 * --sp];
+                } else {
+                    job.finish();
+                    cur = NONE;
+                }
+            }
+        } else if (at_leaf) {  // one primitive of the leaf
+            const int kind = (cur >> 29) & 3;
+            const int count = (cur >> 24) & 31;
+            const int slot = (int)(cur & 0xFFFFFF) + lk;
+            if (kind == rtf::KIND_SPHERE)
+                job.sphere(slot);
+            else
+                job.tri(slot);
+            lk++;
+            const bool stop = job.done();
+            if (stop || lk >= count) {
+                lk = 0;
+                if (!stop && sp) {
+                    cur = stk[64 * --sp];
+                } else {
+                    job.finish();
+                    cur = NONE;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// closest hit of every active path (FindClosestIntersection, raytracer_fs.glsl:241-297)
+// ------------------------------------------------------------------------------------------
+struct WfClosestJob {
+    const WfArgs& a;
+    const GeomBvh& g;
+    float t_lo;  // minDistance: 0 for the primary ray, epsilon after a bounce
+    int p;
+    V3 o, d;
+    BoxRay br;
+    Closest h;
+    __device__ __forceinline__ float t_hi() const { return h.t; }
+    __device__ __forceinline__ bool done() const { return false; }
+    __device__ __forceinline__ void sphere(int slot) {
+        const float4 s = g.sphere(slot);
+        const float t = IntersectSphereT(o, d, v3(s.x, s.y, s.z), s.w);
+        if (closer(t, 0, slot, t_lo, h)) h.t = t, h.kind = 0, h.index = slot;
+    }
+    __device__ __forceinline__ void tri(int slot) {
+        const TriG tg = load_tri(g, slot);
+        const float t = IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N,
+                                                  [&](float tt) { return closer(tt, 2, slot, t_lo, h); });
+        if (closer(t, 2, slot, t_lo, h)) h.t = t, h.kind = 2, h.index = slot;
+    }
+    __device__ __forceinline__ void finish() const {
+        if (a.iter == 0) {
+            a.org_t[p] = make_float4(o.x, o.y, o.z, h.t);
+            a.dir_hit[p] = make_float4(d.x, d.y, d.z, __uint_as_float(wf_pack_hit(h.kind, h.index)));
+        } else {
+            ((float*)(a.org_t + p))[3] = h.t;
+            ((uint32_t*)(a.dir_hit + p))[3] = wf_pack_hit(h.kind, h.index);
+        }
+    }
+    __device__ __forceinline__ bool setup(uint32_t k) {
+        const DevScene& S = a.scene;
+        if (a.iter == 0) {
+            int x, r;
+            p = wf_pixel_of(a, k, &x, &r);
+            if (p < 0) return false;
+            o = v3(a.cam[0], a.cam[1], a.cam[2]);
+            d = primary_direction(a.cam, (float)x + 0.5f, (float)wf_global_row(a, r) + 0.5f);
+        } else {
+            p = (int)wf_list_in(a)[k];
+            const float4 q0 = a.org_t[p], q1 = a.dir_hit[p];
+            o = v3(q0.x, q0.y, q0.z), d = v3(q1.x, q1.y, q1.z);
+        }
+        br = make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
+        h = fresh_closest();
+        for (int q = 0; q < S.n_planes; q++) {
+            const float4 pp = S.plane_geom[2 * q], nn = S.plane_geom[2 * q + 1];
+            const float t = IntersectPlane(o, d, v3(pp.x, pp.y, pp.z), v3(nn.x, nn.y, nn.z));
+            if (closer(t, 1, q, t_lo, h)) h.t = t, h.kind = 1, h.index = q;
+        }
+        if (ray_is_regular(br) && S.n_nodes > 0) return true;
+        // zero direction component etc.: the exact tree, exhaustively (rare)
+        walk<false>(
+            g, S.n_nodes, br, 3, false, nullptr,
+            [&](int slot) {
+                sphere(slot);
+                return false;
+            },
+            [&](int slot) {
+                tri(slot);
+                return false;
+            });
+        finish();
+        return false;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_wf_closest(const WfArgs a) {
+    const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
+    WfClosestJob job{a, g, a.iter == 0 ? 0.0f : RT_EPSILON};
+    wf_run(g, a.counters + 4 * a.iter + 1, wf_active_count(a), job);
+}
+
+// pure flag + "diffuse is not black" of the winning hit (what ObjectInWayOfLight's callers branch on)
+__device__ __forceinline__ void wf_material_flags(const DevScene& S, int kind, int index, bool* pure, bool* diffuse_nz) {
+    const unsigned char* rec;
+    if (kind == 0)
+        rec = S.spheres_aos + (size_t)S.sphere_slot_id[index] * 48 + 16;
+    else if (kind == 1)
+        rec = S.planes_aos + (size_t)index * 64 + 32;
+    else
+        rec = S.tris_aos + (size_t)S.tri_slot_id[index] * 96 + 64;
+    const float4 m0 = *(const float4*)rec;
+    *pure = __float_as_uint(m0.w) != 0u;
+    *diffuse_nz = m0.x != 0 || m0.y != 0 || m0.z != 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// shadow rays of every active path (ObjectInWayOfLight, raytracer_fs.glsl:200-240)
+// Work items are ordered (group of 64 consecutive active paths, light, path in group): the lanes
+// that fetch together get neighbouring hit points and the SAME light, i.e. near-parallel rays that
+// walk the same nodes (L1/L2 hits), not one point's rays to L different lights.
+// ------------------------------------------------------------------------------------------
+struct WfAnyJob {
+    const WfArgs& a;
+    const GeomBvh& g;
+    uint32_t n_active;
+    float t_lo;  // epsilon
+    uint32_t item;
+    V3 o, d;
+    float dist;
+    BoxRay br;
+    bool blocked;
+    __device__ __forceinline__ float t_hi() const { return dist; }
+    __device__ __forceinline__ bool done() const { return blocked; }
+    __device__ __forceinline__ bool in_range(float t) const { return t > RT_EPSILON && t < dist; }
+    __device__ __forceinline__ void sphere(int slot) {
+        const float4 s = g.sphere(slot);
+        if (in_range(IntersectSphereT(o, d, v3(s.x, s.y, s.z), s.w))) blocked = true;
+    }
+    __device__ __forceinline__ void tri(int slot) {
+        const TriG tg = load_tri(g, slot);
+        if (in_range(IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N, [&](float t) { return in_range(t); })))
+            blocked = true;
+    }
+    __device__ __forceinline__ void finish() const { a.blocked[item] = blocked ? 1 : 0; }
+    __device__ __forceinline__ bool setup(uint32_t k) {
+        const DevScene& S = a.scene;
+        const uint32_t L = (uint32_t)a.n_lights;
+        const uint32_t grp = k / (64u * L), in = k - grp * (64u * L);
+        const uint32_t l = in >> 6, j = grp * 64u + (in & 63u);
+        if (j >= n_active) return false;
+        int p;
+        if (a.iter == 0) {
+            int x, r;
+            p = wf_pixel_of(a, j, &x, &r);
+            if (p < 0) return false;
+        } else {
+            p = (int)wf_list_in(a)[j];
+        }
+        const float4 q0 = a.org_t[p], q1 = a.dir_hit[p];
+        const uint32_t hit = __float_as_uint(q1.w);
+        const int kind = (int)(hit >> 28), index = (int)(hit & 0xFFFFFF);
+        if (kind == 3) return false;
+        bool pure, diffuse_nz;
+        wf_material_flags(S, kind, index, &pure, &diffuse_nz);
+        // a mirror bounce only casts shadow rays for a non-black diffuse (raytracer_fs.glsl:340)
+        if (pure && a.iter < a.max_bounces && !diffuse_nz) return false;
+        const V3 hitPos = v3(q0.x, q0.y, q0.z) + q0.w * v3(q1.x, q1.y, q1.z);
+        const LightRay lr = light_ray(S, (int)l, hitPos);
+        o = hitPos, d = lr.L, dist = lr.dist;
+        item = j * L + l;
+        br = make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
+        blocked = false;
+        for (int q = 0; q < S.n_planes && !blocked; q++) {
+            const float4 pp = S.plane_geom[2 * q], nn = S.plane_geom[2 * q + 1];
+            if (in_range(IntersectPlane(o, d, v3(pp.x, pp.y, pp.z), v3(nn.x, nn.y, nn.z)))) blocked = true;
+        }
+        if (!blocked && ray_is_regular(br) && S.n_nodes > 0) return true;
+        if (!blocked)
+            walk<false>(
+                g, S.n_nodes, br, 3, false, nullptr,
+                [&](int slot) {
+                    sphere(slot);
+                    return blocked;
+                },
+                [&](int slot) {
+                    tri(slot);
+                    return blocked;
+                });
+        finish();
+        return false;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_wf_any(const WfArgs a) {
+    const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
+    const uint32_t n_active = wf_active_count(a);
+    WfAnyJob job{a, g, n_active, RT_EPSILON};
+    // the last group of 64 paths is padded: setup() skips j >= n_active
+    wf_run(g, a.counters + 4 * a.iter + 2, ((n_active + 63u) / 64u) * 64u * (uint32_t)a.n_lights, job);
+}
+
+// ------------------------------------------------------------------------------------------
+// shading of every active path for this bounce (raytracer_fs.glsl:328-424), one thread per path
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wf_shade(const WfArgs a) {
+    const DevScene& S = a.scene;
+    const uint32_t total = wf_active_count(a);
+    const uint32_t L = (uint32_t)a.n_lights;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        int p;
+        if (a.iter == 0) {
+            int x, r;
+            p = wf_pixel_of(a, j, &x, &r);
+        } else {
+            p = (int)wf_list_in(a)[j];
+        }
+        bool continues = false;
+        if (p >= 0) {
+            const float4 q0 = a.org_t[p], q1 = a.dir_hit[p];
+            const V3 rayOrigin = v3(q0.x, q0.y, q0.z), rayDirection = v3(q1.x, q1.y, q1.z);
+            V3 mult = v3(1, 1, 1), finalColor = v3(0, 0, 0);
+            if (a.iter > 0) {
+                const float4 m = a.mult_b[p], f = a.final_[p];
+                mult = v3(m.x, m.y, m.z), finalColor = v3(f.x, f.y, f.z);
+            }
+            const uint32_t hit = __float_as_uint(q1.w);
+            Closest h;
+            h.t = q0.w, h.kind = (int)(hit >> 28), h.index = (int)(hit & 0xFFFFFF), h.n = v3(0, 0, 0);
+            if (h.kind == 0) {  // the normal IntersectSphere forms at the accepted t (raytracer_fs.glsl:106-111)
+                const float4 s = S.geom[S.sph_off + h.index];
+                h.n = normalize((rayOrigin + h.t * rayDirection) - v3(s.x, s.y, s.z));
+            }
+            const Surface sf = (h.kind != 3) ? resolve_surface(S, h) : no_surface();
+            if (a.iter == 0 && a.primary_id) a.primary_id[p] = sf.id;
+            const unsigned char* blk = a.blocked + (size_t)j * L;
+            auto in_shadow = [&](int l, const LightRay&) { return blk[l] != 0; };
+            if (sf.pure && a.iter < a.max_bounces) {
+                const V3 hitPos = rayOrigin + h.t * rayDirection;
+                if (sf.diffuse.x != 0 || sf.diffuse.y != 0 || sf.diffuse.z != 0)
+                    finalColor = finalColor + mirror_diffuse_term(S, sf, hitPos, in_shadow) * mult;
+                mult = mult * sf.specular;
+                const V3 refl = mirror_direction(sf, rayDirection);
+                a.org_t[p] = make_float4(hitPos.x, hitPos.y, hitPos.z, RT_FLT_BIG);
+                a.dir_hit[p] = make_float4(refl.x, refl.y, refl.z, __uint_as_float(WF_NO_HIT));
+                a.mult_b[p] = make_float4(mult.x, mult.y, mult.z, 0);
+                a.final_[p] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0);
+                continues = true;
+            } else {
+                PixelOut out;
+                out.primary_id = 0;
+                out.bounces = a.iter;
+                out.final_id = sf.id;
+                if (h.t == RT_FLT_BIG) {
+                    out.rgb = finalColor + v3(0.5f, 0.6f, 1.0f) * mult;
+                } else {
+                    const V3 hitPos = rayOrigin + h.t * rayDirection;
+                    out.rgb = finalColor + phong_term(S, sf, hitPos, rayDirection, in_shadow) * mult;
+                }
+                const size_t i = (size_t)p;
+                if (a.rgb) a.rgb[3 * i] = out.rgb.x, a.rgb[3 * i + 1] = out.rgb.y, a.rgb[3 * i + 2] = out.rgb.z;
+                if (a.rgba8)
+                    a.rgba8[i] = quantise(out.rgb.x) | (quantise(out.rgb.y) << 8) | (quantise(out.rgb.z) << 16) | 0xFF000000u;
+                if (a.final_id) a.final_id[i] = out.final_id;
+                if (a.bounces) a.bounces[i] = out.bounces;
+            }
+        }
+        // append the continuing paths to the next list: ballot + mbcnt compaction, one atomic per wave
+        const unsigned long long mask = __ballot(continues);
+        if (mask) {
+            const int lane = (int)__lane_id(), leader = __ffsll(mask) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(a.counters + 4 * (a.iter + 1), (uint32_t)__popcll(mask));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (continues) wf_list_out(a)[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)p;
+        }
+    }
+}
+
+}  // namespace rtd

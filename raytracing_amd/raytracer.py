@@ -72,7 +72,7 @@ class RayTracer:
             raise RtError(rc, self._lib.rt_last_error(self._ctx).decode())
 
     OPTION_USE_LDS, OPTION_SUPERTILE, OPTION_TRAVERSAL = 1, 2, 3
-    TRAVERSAL_AUTO, TRAVERSAL_WAVE, TRAVERSAL_BVH = 0, 1, 2
+    TRAVERSAL_AUTO, TRAVERSAL_WAVE, TRAVERSAL_BVH, TRAVERSAL_WAVEFRONT = 0, 1, 2, 3
 
     def set_option(self, option, value):
         self._check(self._lib.rt_set_option(self._ctx, int(option), int(value)))

@@ -65,6 +65,36 @@ def test_check_accel_accepts_reference_trees(scene_of):
     assert check_accel(np.zeros(0, np.float32), 0, 0)["n_nodes"] == 0
 
 
+def test_retreed_bvh_sizes(scene_of):
+    """rt_bvh.h through the host-only dry run: one BVH leaf per non-empty reference leaf piece, a binary
+    tree over them plus the root holder, depth within the LDS stack bound; not built for trees whose
+    boxes are not nested."""
+    for name, params in [("TestScene1", None), ("TeapotTable", None), ("Soup", [30000, 300, 4])]:
+        sc = scene_of(name, params)
+        acc = sc.AccelerationStructureData
+        info = check_accel(acc, len(sc.spheresData), len(sc.trianglesData))
+        assert info["flags"] & 1
+        # count the non-empty leaf pieces of the serialised tree (reference leaves hold <= 5 ids of one kind
+        # unless they mix spheres and triangles)
+        S = len(sc.spheresData)
+        pieces, pos_stack = 0, [0]
+        while pos_stack:
+            pos = pos_stack.pop()
+            cnt = int(acc[pos + 7])
+            if acc[pos + 6] == 0:
+                pos_stack += [pos + int(acc[pos + 8 + i]) for i in range(cnt)]
+            else:
+                ids = acc[pos + 8:pos + 8 + cnt]
+                pieces += int((ids < S).any()) + int((ids >= S).any())
+        assert info["bvh_nodes"] == pieces  # (pieces - 1) inner nodes + the root holder
+        assert 1 <= info["bvh_levels"] <= 32
+    sc = scene_of("TestScene1")
+    acc = sc.AccelerationStructureData.copy()
+    acc[3:6] -= 1.0  # root box no longer contains its children
+    info = check_accel(acc, len(sc.spheresData), len(sc.trianglesData))
+    assert info["flags"] == 0 and info["bvh_nodes"] == 0
+
+
 def test_check_accel_rejects_malformed(scene_of):
     sc = scene_of("TestScene1")
     good = sc.AccelerationStructureData

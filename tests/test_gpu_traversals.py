@@ -1,0 +1,158 @@
+"""GPU parity of every fast traversal (wave walk, per-lane BVH megakernel, wavefront pipeline) through
+the C ABI: each must reproduce the oracle's id planes bit for bit and its colours within tolerance,
+and all must agree with the reference-order kernel float for float.  Default renders pick a
+traversal by scene size (RT_TRAVERSAL_AUTO); here every mode is forced on every scene class."""
+import numpy as np
+import pytest
+
+from helpers import assert_frame_matches, oracle_render
+from raytracing_amd import _native as N
+from raytracing_amd.host import Scene
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(1, "wave"), (2, "bvh"), (3, "wavefront")]
+
+
+@pytest.fixture()
+def rt_mode(rt):
+    yield rt
+    rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)
+
+
+def _render(rt, sc, cam, depth, **kw):
+    rt.SendPrimitivesToShader(sc)
+    rt.PrepareRenderOpenGL(cam)
+    return rt.RenderGL(depth, **kw)
+
+
+@pytest.mark.parametrize("mode,label", MODES, ids=[m[1] for m in MODES])
+@pytest.mark.parametrize("name,params,depth", [("TestScene1", None, 10), ("TeapotTable", None, 8),
+                                               ("Soup", [8000, 80, 8], 4)])
+def test_every_traversal_matches_the_oracle(mode, label, name, params, depth, rt_mode, scene_of):
+    from raytracing_amd import host
+    rt = rt_mode
+    sc = scene_of(name, params)
+    rt.set_option(rt.OPTION_TRAVERSAL, mode)
+    g = np.random.default_rng(7)
+    cams = [sc.camera_for(160, 90)]
+    pos = g.uniform([-8, 1, -10], [8, 12, 10])
+    view = g.uniform([-2, 0, -2], [2, 4, 6]) - pos
+    cams.append(host.camera_pack(pos, view, np.cross(view, [0, -1, 0]), 1.0, 1.6, 0.9, 131, 77))
+    for cam in cams:
+        ref = oracle_render(sc, cam, depth, threads=16)
+        out = _render(rt, sc, cam, depth)
+        assert_frame_matches(out, ref, f"{name} {label}")
+    info = rt.scene_info()
+    assert info["flags"] == 3 and info["bvh_nodes"] > 0 and 0 < info["bvh_levels"] <= 32
+
+
+@pytest.mark.parametrize("mode,label", MODES, ids=[m[1] for m in MODES])
+def test_axis_aligned_rays(mode, label, rt_mode):
+    """Rays with exactly zero direction components (1/d infinite, 0*inf = NaN in the box test) must
+    take the exact tree: a camera looking straight down over an odd-sized frame, a light straight
+    above the hit points, boxes whose faces pass through the ray origin."""
+    rt = rt_mode
+    g = np.random.default_rng(3)
+    nt = 60
+    tri = np.zeros(nt, N.TRIANGLE_DT)
+    a = np.round(g.uniform(-4, 4, (nt, 3))) + [0, 3, 0]          # integer coordinates: faces line up with rays
+    b, c = a + np.round(g.uniform(-2, 2, (nt, 3))), a + np.round(g.uniform(-2, 2, (nt, 3)))
+    n = np.cross(b - a, c - a)
+    keep = np.linalg.norm(n, axis=1) > 0
+    tri = tri[keep]
+    a, b, c, n = a[keep], b[keep], c[keep], n[keep]
+    tri["PointA"], tri["PointB"], tri["PointC"] = a, b, c
+    tri["Normal"] = n / np.linalg.norm(n, axis=1, keepdims=True)
+    tri["DiffuseColor"] = g.uniform(0.2, 1, (len(tri), 3))
+    tri["SpecularColor"], tri["Specularity"] = 0.4, 8
+    tri["IsPureSpecular"][::5] = 1
+    sph = np.zeros(4, N.SPHERE_DT)
+    sph["Center"] = [[0, 2, 0], [2, 1, 2], [-3, 1, 1], [1, 4, -2]]
+    sph["Radius"] = 1
+    sph["DiffuseColor"], sph["SpecularColor"], sph["Specularity"] = 0.7, 0.5, 20
+    pl = np.zeros(1, N.PLANE_DT)
+    pl[0]["Position"], pl[0]["Normal"], pl[0]["DiffuseColor"] = [0, 0, 0], [0, 1, 0], [0.5, 0.5, 0.5]
+    pl[0]["IsPureSpecular"], pl[0]["SpecularColor"], pl[0]["Specularity"] = 1, [0.6, 0.6, 0.6], 1
+    from raytracing_amd import host
+    accel = host.accel_from_structs(sph, tri)
+    lights = np.array([0, 20, 0, 300, 300, 300, 2, 20, 2, 200, 100, 50], np.float32)
+    # camera at (0, 20, 0) looking down -y: the middle column and row have a zero direction component,
+    # the centre pixel has two
+    cam = host.camera_pack([0, 20, 0], [0, -1, 0], [1, 0, 0], 1.0, 1.0, 1.0, 33, 33)
+    sc = Scene(sph, pl, tri, accel, lights, cam)
+    ref = oracle_render(sc, cam, 4)
+    assert (ref["primary_id"] >= 0).all()
+    rt.set_option(rt.OPTION_TRAVERSAL, mode)
+    out = _render(rt, sc, cam, 4)
+    assert_frame_matches(out, ref, "axis-aligned " + label)
+    slow = _render(rt, sc, cam, 4, stats=True)
+    assert np.array_equal(out["rgb"].view(np.uint32), slow["rgb"].view(np.uint32))
+
+
+@pytest.mark.parametrize("mode,label", MODES, ids=[m[1] for m in MODES])
+def test_equal_t_across_leaves_takes_the_first_in_reference_order(mode, label, rt_mode):
+    """Twelve coincident triangles spread over several leaves give bit-identical t on every ray: the
+    reference accepts on strict <, so the first candidate of its visit order wins.  An ordered
+    traversal meets the leaves in a ray-dependent order and must carry that rank explicitly."""
+    from raytracing_amd import host
+    rt = rt_mode
+    nt = 12
+    tri = np.zeros(nt, N.TRIANGLE_DT)
+    tri["PointA"], tri["PointB"], tri["PointC"] = [-5, -4, 6], [5, -5, 5], [1, 5, 4]
+    n = np.cross(np.array([10, -1, -1.0]), np.array([6, 9, -2.0]))
+    tri["Normal"] = n / np.linalg.norm(n)
+    tri["DiffuseColor"] = np.linspace(0.1, 1, nt)[:, None]
+    accel = host.accel_from_structs(np.zeros(0, N.SPHERE_DT), tri)
+    cam = np.array([0, 0, 0, -0.8, -0.45, 1, 0.8, -0.45, 1, -0.8, 0.45, 1, 64, 36], np.float32)
+    lights = np.array([0, 0, 0, 5, 5, 5], np.float32)
+    sc = Scene(np.zeros(0, N.SPHERE_DT), np.zeros(0, N.PLANE_DT), tri, accel, lights, cam)
+    ref = oracle_render(sc, cam, 2)
+    hit = ref["primary_id"][ref["primary_id"] >= 0]
+    assert len(hit) > 200 and len(np.unique(hit)) == 1
+    rt.set_option(rt.OPTION_TRAVERSAL, mode)
+    assert_frame_matches(_render(rt, sc, cam, 2), ref, "coincident " + label)
+
+
+def test_hand_made_tree_without_nesting_falls_back(rt_mode, scene_of):
+    """A tree whose child boxes stick out of their parent is legal input (the shader only ever tests
+    the boxes it is given).  The re-treed BVH and the distance cull both rely on nesting, so the
+    library must notice and render with the exact tree whatever traversal is asked for."""
+    rt = rt_mode
+    sc = scene_of("TeapotScene")
+    accel = sc.AccelerationStructureData.copy()
+    accel[0:3] += 0.75   # shrink the root box from below: children now stick out
+    bad = Scene(sc.spheresData, sc.planesData, sc.trianglesData, accel, sc.lightsData, sc.cameraData)
+    cam = bad.camera_for(160, 90)
+    ref = oracle_render(bad, cam, 1)
+    good_ref = oracle_render(sc, cam, 1)
+    assert not np.array_equal(ref["primary_id"], good_ref["primary_id"])  # the shrunken root does hide hits
+    for mode, label in MODES + [(0, "auto")]:
+        rt.set_option(rt.OPTION_TRAVERSAL, mode)
+        out = _render(rt, bad, cam, 1)
+        info = rt.scene_info()
+        assert info["flags"] == 0 and info["bvh_nodes"] == 0
+        assert_frame_matches(out, ref, "not nested " + label)
+
+
+def test_all_traversals_agree_at_full_size_soup1m(rt_mode, scene_of):
+    """BASELINE config 3 (Soup1M, 3840x2160, depth 4): the id planes and float colours of the wavefront
+    pipeline, the BVH megakernel and the reference-order kernel must be identical, and a crop must match
+    the oracle.  (This is the frame on which two intersecting triangles produce bit-identical t.)"""
+    rt = rt_mode
+    sc = scene_of("Soup", [1_000_000, 10_000, 8])
+    cam = sc.camera_for(3840, 2160)
+    want = ("rgb", "primary_id", "final_id")
+    slow = _render(rt, sc, cam, 4, want=want, stats=True)
+    st = slow["stats"]
+    assert st["primary_rays"] == 3840 * 2160
+    for mode, label in [(3, "wavefront"), (2, "bvh"), (0, "auto")]:
+        rt.set_option(rt.OPTION_TRAVERSAL, mode)
+        fast = _render(rt, sc, cam, 4, want=want)
+        assert np.array_equal(fast["primary_id"], slow["primary_id"]), label
+        assert np.array_equal(fast["final_id"], slow["final_id"]), label
+        assert np.array_equal(fast["rgb"].view(np.uint32), slow["rgb"].view(np.uint32)), label
+    x0, y0, x1, y1 = 1440, 960, 1504, 1000   # contains pixel (1472, 985), the equal-t pixel
+    ref = oracle_render(sc, cam, 4, threads=16, region=(x0, y0, x1, y1))
+    crop = {k: v[y0:y1, x0:x1] for k, v in slow.items() if k in want}
+    assert_frame_matches(crop, ref, "soup1m crop")

@@ -18,7 +18,7 @@ for name in names:
     info = rt.scene_info()
     cam = sc.camera_for(w, h)
     res = {}
-    for mode, label in ((1, "wave"), (2, "bvh")):
+    for mode, label in ((1, "wave"), (2, "bvh"), (3, "wf")):
         rt.set_option(rt.OPTION_TRAVERSAL, mode)
         pid = torch.empty((h, w), dtype=torch.int32, device="cuda")
         fid = torch.empty((h, w), dtype=torch.int32, device="cuda")
@@ -36,7 +36,7 @@ for name in names:
         rt.render_device(cam, d, rgba8=rgba.data_ptr(), primary_id=pid.data_ptr(), final_id=fid.data_ptr(),
                          bounces=bnc.data_ptr(), reference_order=True, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        for label in ("wave", "bvh"):
+        for label in ("wave", "bvh", "wf"):
             r = res[label]
             dp = (r[0] != pid); df = (r[1] != fid)
             print(f"  {label} vs reference-order: primary_id diffs {int(dp.sum())}, final_id diffs {int(df.sum())}, "
@@ -45,10 +45,10 @@ for name in names:
                 idx = dp.nonzero()[:5].cpu().numpy()
                 for (yy, xx) in idx:
                     print(f"    px ({xx},{yy}): {label} {int(r[0][yy, xx])} ref {int(pid[yy, xx])}")
-    a, b = res["wave"], res["bvh"]
-    same = [bool(torch.equal(a[k], b[k])) for k in range(4)]
+    a, b, c = res["wave"], res["bvh"], res["wf"]
+    same = [bool(torch.equal(a[k], b[k])) and bool(torch.equal(a[k], c[k])) for k in range(4)]
     st = B.device_stats(rt, torch, cam, d)
     rays = B.total_rays(st)
     print(f"{name:22s} build {t1-t0:5.2f}s upload {t2-t1:5.2f}s nodes {info['n_nodes']} bvh {info['bvh_nodes']} "
-          f"levels {info['bvh_levels']} flags {info['flags']} | wave {a[4]:9.3f} ms  bvh {b[4]:9.3f} ms "
-          f"({rays/b[4]/1e3:9.1f} Mrays/s) | identical pid/fid/bounces/rgba8: {same}", flush=True)
+          f"levels {info['bvh_levels']} flags {info['flags']} | wave {a[4]:9.3f} ms  bvh {b[4]:9.3f} ms  wf {c[4]:9.3f} ms "
+          f"({rays/min(b[4],c[4])/1e3:9.1f} Mrays/s) | identical pid/fid/bounces/rgba8: {same}", flush=True)
