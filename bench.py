@@ -27,6 +27,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+KERNEL_OF = {1: "k_render<false> (wave-cooperative walk)", 2: "k_render_bvh (per-lane BVH, LDS stacks)",
+             3: "k_wf_closest + k_wf_any + k_wf_shade per bounce (wavefront pipeline, whole frame)"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BAND_ROWS = 16
 
@@ -260,7 +262,7 @@ def main():
             "ray_breakdown_frame0": {k: st0[k] for k in ("primary_rays", "secondary_rays", "shadow_rays")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_render<false>", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": KERNEL_OF.get(rt.scene_info()["traversal"], "?"), "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "algorithmic bytes of the REFERENCE algorithm (SURVEY 8d); this scene is "
                                  "L2-resident, so the binding limit is VALU issue, not HBM"},
@@ -286,7 +288,8 @@ def main():
                 big = name.startswith("soup")
                 ms = time_single(rt, torch, cam, d, w, h, 3 if big else 20, 1 if big else 3)
                 ab = algorithmic_bytes(st, w, h)
-                extras[name] = {"ms_per_frame": round(ms, 4), "Mrays_per_s": round(total_rays(st) / ms / 1e3, 1),
+                extras[name] = {"traversal": KERNEL_OF.get(rt.scene_info()["traversal"], "?").split(" ")[0],
+                                "ms_per_frame": round(ms, 4), "Mrays_per_s": round(total_rays(st) / ms / 1e3, 1),
                                 "rays": total_rays(st), "algorithmic_GBps": round(ab / ms / 1e6, 1),
                                 "scene_build_s": round(t_build, 2)}
             result["extra"] = extras

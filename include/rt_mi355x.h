@@ -148,7 +148,8 @@ typedef struct rt_scene_info {
     int64_t bvh_nodes;      /* 64-byte nodes of the re-treed leaves (0 = not built)    */
     int64_t bvh_levels;     /* LDS stack entries per lane the BVH kernel reserves      */
     int64_t flags;          /* RT_SCENE_*                                              */
-    int64_t reserved[3];
+    int64_t traversal;      /* RT_TRAVERSAL_* a default render (max_bounces 10) uses   */
+    int64_t reserved[2];
 } rt_scene_info;
 enum {
     RT_SCENE_NESTED = 1,    /* every box lies inside its parent's (true for every RTree.cs tree) */

@@ -95,7 +95,18 @@ void release(DevBuf& b) {
     b.bytes = 0;
 }
 
-bool r_max_ok(const rt_ctx* ctx, int max_bounces) { return max_bounces <= ctx->wf_max_bounces; }
+// Which fast kernel renders this scene (RT_TRAVERSAL_WAVE / BVH / WAVEFRONT) under the context's
+// RT_OPTION_TRAVERSAL: the re-treed kernels need the BVH (nested trees only); the staged pipeline is
+// for large scenes and a bounded number of bounces.
+int pick_traversal(const rt_ctx* ctx, const DevScene& sc, int max_bounces) {
+    const bool bvh_ok = sc.bvh != nullptr && sc.bvh_levels <= rtb::MAX_LEVELS;
+    if (!bvh_ok || ctx->traversal == RT_TRAVERSAL_WAVE) return RT_TRAVERSAL_WAVE;
+    const bool wf_ok = max_bounces <= ctx->wf_max_bounces;
+    if (ctx->traversal == RT_TRAVERSAL_WAVEFRONT) return wf_ok ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
+    if (ctx->traversal == RT_TRAVERSAL_BVH) return RT_TRAVERSAL_BVH;
+    if (wf_ok && sc.n_nodes >= ctx->wf_min_nodes) return RT_TRAVERSAL_WAVEFRONT;
+    return sc.n_nodes >= ctx->bvh_min_nodes ? RT_TRAVERSAL_BVH : RT_TRAVERSAL_WAVE;
+}
 
 int camera_size(const float* cam, int* w, int* h) {
     if (!cam) return RT_ERR_INVALID_ARGUMENT;
@@ -424,6 +435,7 @@ int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out) {
     if (!ctx || !out) return RT_ERR_INVALID_ARGUMENT;
     if (!ctx->has_scene) return RT_ERR_NO_SCENE;
     *out = ctx->info;
+    out->traversal = pick_traversal(ctx, ctx->scene, 10);
     return RT_OK;
 }
 
@@ -475,12 +487,8 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
         HIP_TRY(ctx, hipGetLastError());
         return RT_OK;
     }
-    const bool bvh_ok = a.scene.bvh != nullptr && a.scene.bvh_levels <= rtb::MAX_LEVELS;
-    const bool use_bvh = bvh_ok && (ctx->traversal == RT_TRAVERSAL_BVH ||
-                                    (ctx->traversal == RT_TRAVERSAL_AUTO && a.scene.n_nodes >= ctx->bvh_min_nodes));
-    const bool use_wf = bvh_ok && r_max_ok(ctx, max_bounces) &&
-                        (ctx->traversal == RT_TRAVERSAL_WAVEFRONT ||
-                         (ctx->traversal == RT_TRAVERSAL_AUTO && a.scene.n_nodes >= ctx->wf_min_nodes));
+    const int trav = pick_traversal(ctx, a.scene, max_bounces);
+    const bool use_wf = trav == RT_TRAVERSAL_WAVEFRONT, use_bvh = trav == RT_TRAVERSAL_BVH;
     if (flags & RT_RENDER_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
     else if (use_wf)
