@@ -208,6 +208,10 @@ int rt_create(int device_id, rt_ctx** out) {
             ctx->lds_limit = std::min<int>(ctx->lds_limit, (int)prop.maxSharedMemoryPerMultiProcessor);
     }
     if (const char* v = getenv("RT_USE_LDS")) ctx->allow_lds = atoi(v) != 0;
+    if (const char* v = getenv("RT_WF_WAVES")) {  // development: persistent waves per CU of the trace stages
+        const int t = atoi(v);
+        if (t >= 1 && t <= 64) ctx->wf_waves_per_cu = t;
+    }
     if (const char* v = getenv("RT_TRAVERSAL")) {  // development override of RT_OPTION_TRAVERSAL
         const int t = atoi(v);
         if (t >= RT_TRAVERSAL_AUTO && t <= RT_TRAVERSAL_WAVEFRONT) ctx->traversal = t;

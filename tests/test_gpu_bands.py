@@ -8,8 +8,15 @@ from raytracing_amd import parallel as P
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 1, 3], ids=["auto", "wave", "wavefront"])
+def traversal(request, rt):
+    rt.set_option(rt.OPTION_TRAVERSAL, request.param)
+    yield request.param
+    rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)
+
+
 @pytest.mark.parametrize("w,h,band,world", [(160, 90, 16, 2), (123, 77, 8, 3), (320, 180, 16, 8), (64, 20, 32, 2)])
-def test_bands_assemble_to_the_full_frame(w, h, band, world, rt, scene_of):
+def test_bands_assemble_to_the_full_frame(w, h, band, world, rt, scene_of, traversal):
     sc = scene_of("TestScene1")
     cam = sc.camera_for(w, h)
     rt.SendPrimitivesToShader(sc)
