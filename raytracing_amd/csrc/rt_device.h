@@ -23,6 +23,8 @@ using namespace rtm;
 //   [0, 2*n_nodes)                      2 x float4 per node (rtf::FlatNode)
 //   [tri_off, tri_off + 3*n_tri_slots)  3 x float4 per triangle slot: A.xyz B.x | B.yz C.xy | C.z N.xyz
 //   [sph_off, sph_off + n_sph_slots)    1 x float4 per sphere slot: center.xyz radius
+//   [bvh_off, geom_float4s)             4 x float4 per node of the re-treed leaves (rt_bvh.h)
+// The part from tri_off on is what the LDS-resident kernel copies into a workgroup's LDS.
 struct DevScene {
     const float4* geom;
     int32_t tri_off, sph_off, geom_float4s;
@@ -39,9 +41,11 @@ struct DevScene {
     // upload could not verify that every primitive lies inside its leaf box and every box inside its
     // parent (hand-made accel arrays; the cull's proof needs both)
     float cull_scale;
-    // re-treed leaves (rt_bvh.h): 4 x float4 per node, node 0 = root holder; null if not built
+    // re-treed leaves (rt_bvh.h): 4 x float4 per node, node 0 = root holder; null if not built.
+    // They sit at the end of the geometry image (bvh == geom + bvh_off).
     const float4* bvh;
     int32_t bvh_levels;  // stack entries a traversal can need
+    int32_t bvh_off;
 };
 
 struct GeomGlobal {
@@ -52,9 +56,6 @@ struct GeomGlobal {
     __device__ __forceinline__ float4 tri(int slot, int k) const { return base[tri_off + 3 * slot + k]; }
     __device__ __forceinline__ float4 sphere(int slot) const { return base[sph_off + slot]; }
 };
-// dynamic LDS of the LDS-resident kernel; named directly (not through a generic pointer) so that
-// every access is a ds_read_b128, never a flat load
-extern __shared__ float4 rt_lds[];
 // geometry in HBM/L2 + the re-treed leaves, walked per lane with a stack in LDS (bvh_walk)
 struct GeomBvh {
     const float4* base;
@@ -68,6 +69,26 @@ struct GeomBvh {
     __device__ __forceinline__ float4 node_hi(int i) const { return base[2 * i + 1]; }
     __device__ __forceinline__ float4 tri(int slot, int k) const { return base[tri_off + 3 * slot + k]; }
     __device__ __forceinline__ float4 sphere(int slot) const { return base[sph_off + slot]; }
+    __device__ __forceinline__ float4 bvh_node(uint32_t i, int k) const { return bvh[4 * (size_t)i + k]; }
+};
+// dynamic LDS of the kernels that use it; named directly (not through a generic pointer) so that
+// every access is a ds_read / ds_write, never a flat access
+extern __shared__ float4 rt_lds[];
+// The same, with triangle slots, sphere slots and BVH nodes resident in the workgroup's LDS (small
+// scenes): rt_lds[0 ..) holds geometry image [tri_off, geom_float4s).  The exact flat tree (only
+// walked by rays with a zero direction component) stays in global memory.
+struct GeomBvhLds {
+    const float4* base;
+    int sph_l, bvh_l;  // float4 index of the sphere slots / BVH nodes inside rt_lds
+    int stack_base;
+#ifdef RT_DIAG_STEPS
+    int* diag;
+#endif
+    __device__ __forceinline__ float4 node_lo(int i) const { return base[2 * i]; }
+    __device__ __forceinline__ float4 node_hi(int i) const { return base[2 * i + 1]; }
+    __device__ __forceinline__ float4 tri(int slot, int k) const { return rt_lds[3 * slot + k]; }
+    __device__ __forceinline__ float4 sphere(int slot) const { return rt_lds[sph_l + slot]; }
+    __device__ __forceinline__ float4 bvh_node(uint32_t i, int k) const { return rt_lds[bvh_l + 4 * (int)i + k]; }
 };
 template <class G>
 struct is_bvh {
@@ -77,12 +98,9 @@ template <>
 struct is_bvh<GeomBvh> {
     static constexpr bool value = true;
 };
-struct GeomLds {
-    int tri_off, sph_off;
-    __device__ __forceinline__ float4 node_lo(int i) const { return rt_lds[2 * i]; }
-    __device__ __forceinline__ float4 node_hi(int i) const { return rt_lds[2 * i + 1]; }
-    __device__ __forceinline__ float4 tri(int slot, int k) const { return rt_lds[tri_off + 3 * slot + k]; }
-    __device__ __forceinline__ float4 sphere(int slot) const { return rt_lds[sph_off + slot]; }
+template <>
+struct is_bvh<GeomBvhLds> {
+    static constexpr bool value = true;
 };
 
 constexpr float RT_FLT_BIG = 3.402823466e+38f;  // raytracer_fs.glsl:315

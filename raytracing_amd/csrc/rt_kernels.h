@@ -116,21 +116,29 @@ __device__ __forceinline__ void wave_walk(const G& g, int n_nodes, const BoxRay&
 #ifdef RT_DIAG_STEPS  // diagnostic build only: per-lane step counters of bvh_walk (tools/diag_steps.py)
 #define rt_diag g.diag
 #endif
-template <class LeafSphere, class LeafTri, class Done, class THi>
-__device__ __forceinline__ void bvh_walk(const GeomBvh& g, const BoxRay& br, bool alive, float t_lo, THi&& t_hi,
+// Entry of a traversal: node 0 only holds the root (box + ref) as its child 0, so one box test decides
+// whether the ray walks anything at all.  Returns the root's ref or NONE.
+template <class G>
+__device__ __forceinline__ uint32_t bvh_enter(const G& g, const BoxRay& br, float t_lo, float t_hi) {
+    const float4 q0 = g.bvh_node(0, 0), q1 = g.bvh_node(0, 1);
+    return IntersectBoundingBoxCull(br, q0, q1, t_lo, t_hi) ? __float_as_uint(q0.w) : 0xFFFFFFFFu;
+}
+
+template <class G, class LeafSphere, class LeafTri, class Done, class THi>
+__device__ __forceinline__ void bvh_walk(const G& g, const BoxRay& br, bool alive, float t_lo, THi&& t_hi,
                                          LeafSphere&& on_sphere, LeafTri&& on_tri, Done&& done) {
     constexpr uint32_t NONE = 0xFFFFFFFFu, LEAF = 0x80000000u;
     uint32_t* const stk = (uint32_t*)rt_lds + g.stack_base;
     int sp = 0;
-    uint32_t cur = alive ? 0u : NONE;
+    uint32_t cur = NONE;
+    if (alive) cur = bvh_enter(g, br, t_lo, t_hi());
     while (cur != NONE) {
         while (!(cur & LEAF)) {
 #ifdef RT_DIAG_STEPS
             rt_diag[0]++;
             if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) rt_diag[2]++;
 #endif
-            const float4* nd = g.bvh + 4 * (size_t)cur;
-            const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+            const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2), q3 = g.bvh_node(cur, 3);
             const float th = t_hi();
             float e0, e1;
             const bool h0 = IntersectBoundingBoxCull(br, q0, q1, t_lo, th, &e0);
@@ -547,7 +555,11 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 
 // ---- large scenes: per-lane ordered traversal of the re-treed leaves, stacks in LDS ----------------
 // Same pixel mapping as k_render; dynamic LDS = BLOCK_WAVES * 64 lanes * bvh_levels dwords.
-__global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render_bvh(const RenderArgs a) {
+#ifndef RT_BVH_WAVES_PER_EU
+#define RT_BVH_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(64 * BLOCK_WAVES) __attribute__((amdgpu_waves_per_eu(RT_BVH_WAVES_PER_EU, 8))) void k_render_bvh(
+    const RenderArgs a) {
     int tx, ty;
     const bool in_image = block_to_tile(blockIdx.x, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -576,33 +588,42 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render_bvh(const RenderArg
     }
 }
 
-// ---- geometry in LDS: persistent workgroups, waves pull 8x8 tiles from a ticket counter --------
-// A scene whose flattened geometry fits the CU's 160 KB LDS is copied there once per workgroup
-// (one 1024-thread workgroup per CU, grid = number of CUs).  Every node/triangle fetch of the
-// traversal is then a ds_read_b128 instead of a scattered 16-byte gather through the vector
-// memory pipeline, which is what bounds k_render on such scenes (profiles/).
-// Work distribution: each wave draws tickets (one 8x8 pixel tile each) from one device-scope
-// counter until the frame is exhausted -- dynamic balance between sky and mesh tiles, and every
-// wave reaches the exit condition (ticket >= n_tiles), so the grid always drains.  The counter is
-// never reset: the host passes the first ticket of this launch (ticket_base) and advances it by
-// n_tiles + number of waves, which is exactly what the launch consumes.
+// ---- small scenes: the same per-lane traversal with triangles, spheres and BVH nodes in LDS ---------
+// One 1024-thread workgroup per CU copies geometry image [tri_off, geom_float4s) into LDS once
+// (teapot scene: 70 KB), the per-lane stacks follow it.  Every node and triangle fetch of the
+// traversal is then a ds_read_b128 (tens of cycles) instead of a gather through L1/L2 (hundreds),
+// which is what the 4 waves per SIMD of the megakernel cannot hide.
+// Work distribution: each wave draws tickets (one 8x8 pixel tile each, in the XCD-interleaved
+// super-tile order of block_to_tile) from one device-scope counter until the frame is exhausted --
+// dynamic balance between sky and mesh tiles, and every wave reaches the exit condition
+// (ticket >= n_tickets), so the grid always drains.  The counter is never reset: the host passes
+// the first ticket of this launch (ticket_base) and advances it by n_tickets + number of waves,
+// which is exactly what the launch consumes.
 constexpr int LDS_BLOCK = 1024;
-__global__ __launch_bounds__(LDS_BLOCK) void k_render_lds(const RenderArgs a) {
-    for (int i = threadIdx.x; i < a.scene.geom_float4s; i += LDS_BLOCK) rt_lds[i] = a.scene.geom[i];
+__global__ __launch_bounds__(LDS_BLOCK) void k_render_bvh_lds(const RenderArgs a) {
+    const int n_copy = a.scene.geom_float4s - a.scene.tri_off;
+    for (int i = threadIdx.x; i < n_copy; i += LDS_BLOCK) rt_lds[i] = a.scene.geom[a.scene.tri_off + i];
     __syncthreads();
-    const GeomLds g{a.scene.tri_off, a.scene.sph_off};
-    const int lane = threadIdx.x & 63;
-    const int tiles_x = (a.width + 7) >> 3, tiles_y = (a.local_rows + 7) >> 3;
-    const unsigned int n_tiles = (unsigned int)(tiles_x * tiles_y);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const GeomBvhLds g{a.scene.geom, a.scene.sph_off - a.scene.tri_off, a.scene.bvh_off - a.scene.tri_off,
+                       n_copy * 4 + wave * 64 * a.scene.bvh_levels + lane};
+    const int per = a.supertile * a.supertile;
+    const int n_super = ((a.tiles_x + a.supertile - 1) / a.supertile) * ((a.tiles_y + a.supertile - 1) / a.supertile);
+    const unsigned int n_tickets = (unsigned int)(n_super * per);
     for (;;) {
         unsigned int t = 0;
         if (lane == 0) t = atomicAdd(a.ticket, 1u) - a.ticket_base;
         t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= n_tiles) break;
-        const int x = (int)(t % tiles_x) * 8 + (lane & 7);
-        const int r = (int)(t / tiles_x) * 8 + (lane >> 3);
-        const int y = global_row(a, r);
-        if (x < a.width && r < a.local_rows && y < a.height) {
+        if (t >= n_tickets) break;
+        // ticket -> tile: consecutive tickets walk one super-tile
+        const int super = (int)(t / per), in = (int)(t % per);
+        const int sx_n = (a.tiles_x + a.supertile - 1) / a.supertile;
+        const int tx = (super % sx_n) * a.supertile + in % a.supertile;
+        const int ty = (super / sx_n) * a.supertile + in / a.supertile;
+        const int x = tx * 8 + (lane & 7);
+        const int r = ty * 8 + (lane >> 3);
+        if (tx < a.tiles_x && ty < a.tiles_y && x < a.width && r < a.local_rows) {
+            const int y = global_row(a, r);
             const PixelOut p =
                 shade_pixel<false>(a.scene, g, a.cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, nullptr);
             store_pixel(a, x, r, p);

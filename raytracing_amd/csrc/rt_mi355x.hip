@@ -33,17 +33,18 @@ struct rt_ctx {
     DevScene scene{};
     rt_scene_info info{};
     // scene buffers
-    DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights, bvh;
+    DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights;
     int traversal = RT_TRAVERSAL_AUTO;  // RT_OPTION_TRAVERSAL
     int bvh_min_nodes = 0;              // auto: scenes with at least this many flat nodes take the BVH kernel
                                         // (measured faster than the wave walk on every scene)
-    // LDS-resident persistent kernel (k_render_lds)
+    // LDS-resident persistent kernel (k_render_bvh_lds)
     DevBuf ticket;
     unsigned int ticket_base = 0;
     int n_cus = 256;
-    bool lds_capable = false;   // the scene's geometry image fits the CU's LDS
+    bool lds_capable = false;   // triangle/sphere slots + BVH nodes + the per-lane stacks fit the CU's LDS
+    size_t lds_bytes = 0;       // dynamic LDS the LDS-resident kernel needs for this scene
     int lds_limit = 160 * 1024;  // bytes of dynamic LDS one workgroup may take (160 KB per CU)
-    bool allow_lds = false;     // opt-in (RT_OPTION_USE_LDS): measured slower than the scalar-load walk
+    bool allow_lds = false;     // RT_OPTION_USE_LDS: opt-in, measured slower than the L2-resident walk
     // path state of the wavefront pipeline (rt_wavefront.h; grow only)
     DevBuf wf_org, wf_dir, wf_mult, wf_final, wf_list0, wf_list1, wf_blocked, wf_counters;
     int wf_min_nodes = 100000; // auto: scenes with at least this many flat nodes take the wavefront pipeline
@@ -218,7 +219,7 @@ int rt_create(int device_id, rt_ctx** out) {
     }
     // the persistent kernel's ticket counter: zeroed once, never reset (rt_kernels.h)
     if (hipMalloc(&ctx->ticket.p, 256) != hipSuccess || hipMemset(ctx->ticket.p, 0, 256) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_render_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)k_render_bvh_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                             ctx->lds_limit) != hipSuccess) {
         (void)hipGetLastError();
         ctx->allow_lds = false;  // the global-memory kernel needs none of this
@@ -233,7 +234,6 @@ void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    release(ctx->bvh);
     DevBuf* wf[] = {&ctx->wf_org,   &ctx->wf_dir,   &ctx->wf_mult,    &ctx->wf_final,
                     &ctx->wf_list0, &ctx->wf_list1, &ctx->wf_blocked, &ctx->wf_counters};
     for (DevBuf* b : wf) release(*b);
@@ -291,13 +291,20 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     if ((rc = upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), flat.sphere_slot_id.size() * 4)))
         return rc;
     const int n_ts = (int)flat.tri_slot_id.size(), n_ss = (int)flat.sphere_slot_id.size();
-    // one contiguous geometry image: nodes | triangle slots | sphere slots (rt_device.h)
+    // re-treed leaves for the per-lane kernels (only for nested trees, rt_bvh.h)
+    rtb::Bvh bvh;
+    if (flat.nested) rtb::build(flat, &bvh);
+    // one contiguous geometry image: nodes | triangle slots | sphere slots | BVH nodes (rt_device.h)
     const size_t tri_off = flat.nodes.size() * 2, sph_off = tri_off + (size_t)n_ts * 3;
-    const size_t geom_f4 = sph_off + (size_t)n_ss;
+    const size_t bvh_off = sph_off + (size_t)n_ss;
+    const size_t geom_f4 = bvh_off + bvh.nodes.size() * 4;
     if (geom_f4 >= (size_t)INT32_MAX / 2) return fail(ctx, RT_ERR_TOO_LARGE, "geometry image too large");
     if ((rc = ensure(ctx, ctx->geom, geom_f4 * 16))) return rc;
     if (!flat.nodes.empty())
         HIP_TRY(ctx, hipMemcpy(ctx->geom.p, flat.nodes.data(), flat.nodes.size() * 32, hipMemcpyHostToDevice));
+    if (!bvh.nodes.empty())
+        HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + bvh_off, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtb::Node),
+                               hipMemcpyHostToDevice));
     if ((rc = ensure(ctx, ctx->plane_geom, (size_t)n_planes * 32))) return rc;
     float4* const tri_geom = (float4*)ctx->geom.p + tri_off;
     float4* const sphere_geom = (float4*)ctx->geom.p + sph_off;
@@ -372,18 +379,9 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     }
     s.cull_scale = contained ? 0.0078125f : INFINITY;
 
-    // re-treed leaves for the per-lane kernel (only for nested trees, rt_bvh.h)
-    s.bvh = nullptr;
-    s.bvh_levels = 0;
-    rtb::Bvh bvh;
-    if (flat.nested) {
-        rtb::build(flat, &bvh);
-        if (!bvh.nodes.empty()) {
-            if ((rc = upload(ctx, ctx->bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtb::Node)))) return rc;
-            s.bvh = (const float4*)ctx->bvh.p;
-            s.bvh_levels = bvh.levels;
-        }
-    }
+    s.bvh = bvh.nodes.empty() ? nullptr : (const float4*)ctx->geom.p + bvh_off;
+    s.bvh_levels = bvh.levels;
+    s.bvh_off = (int32_t)bvh_off;
 
     rt_scene_info& inf = ctx->info;
     std::memset(&inf, 0, sizeof inf);
@@ -394,12 +392,13 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     inf.device_bytes = (int64_t)(flat.nodes.size() * 32 + (size_t)n_ts * 52 + (size_t)n_ss * 20 +
                                  (size_t)n_planes * 96 + (size_t)n_spheres * 48 + (size_t)n_triangles * 96 +
                                  (size_t)lights_len * 4);
-    inf.lds_scene_bytes = (int64_t)(geom_f4 * 16);
+    ctx->lds_bytes = (geom_f4 - tri_off) * 16 + (size_t)LDS_BLOCK * std::max(bvh.levels, 1) * 4;
+    inf.lds_scene_bytes = (int64_t)ctx->lds_bytes;
     inf.bvh_nodes = (int64_t)bvh.nodes.size();
     inf.bvh_levels = bvh.levels;
     inf.flags = (flat.nested ? RT_SCENE_NESTED : 0) | (contained ? RT_SCENE_CULL : 0);
     inf.device_bytes += (int64_t)(bvh.nodes.size() * sizeof(rtb::Node));
-    ctx->lds_capable = geom_f4 > 0 && geom_f4 * 16 <= (size_t)ctx->lds_limit;
+    ctx->lds_capable = !bvh.nodes.empty() && ctx->lds_bytes <= (size_t)ctx->lds_limit;
     ctx->has_scene = true;
     return RT_OK;
 }
@@ -479,25 +478,23 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
     a.ticket_base = 0;
     if (a.tiles_y == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (!(flags & (RT_RENDER_REFERENCE_ORDER | RT_RENDER_GLOBAL_MEMORY)) && ctx->allow_lds && ctx->lds_capable) {
-        // LDS-resident persistent kernel: one workgroup per CU; each of its waves draws one ticket
-        // past the end, so the launch consumes exactly n_tiles + n_waves tickets
-        const unsigned int n_tiles8 = (unsigned int)(((w + 7) / 8) * ((a.local_rows + 7) / 8));
-        const int grid = (int)std::min<unsigned int>((unsigned int)ctx->n_cus, (n_tiles8 + 15) / 16);
-        a.ticket = (unsigned int*)ctx->ticket.p;
-        a.ticket_base = ctx->ticket_base;
-        ctx->ticket_base += n_tiles8 + (unsigned int)grid * (LDS_BLOCK / 64);
-        hipLaunchKernelGGL(k_render_lds, dim3(grid), dim3(LDS_BLOCK), (size_t)a.scene.geom_float4s * 16, st, a);
-        HIP_TRY(ctx, hipGetLastError());
-        return RT_OK;
-    }
     const int trav = pick_traversal(ctx, a.scene, max_bounces);
     const bool use_wf = trav == RT_TRAVERSAL_WAVEFRONT, use_bvh = trav == RT_TRAVERSAL_BVH;
     if (flags & RT_RENDER_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
     else if (use_wf)
         return launch_wavefront(ctx, a, st);
-    else if (use_bvh)
+    else if (use_bvh && !(flags & RT_RENDER_GLOBAL_MEMORY) && ctx->allow_lds && ctx->lds_capable && ctx->ticket.p) {
+        // LDS-resident persistent kernel: one workgroup per CU; each of its waves draws one ticket
+        // past the end, so the launch consumes exactly n_tickets + n_waves tickets
+        const int per = a.supertile * a.supertile;
+        const unsigned int n_tickets = (unsigned int)(n_super * per);
+        const int grid = (int)std::min<unsigned int>((unsigned int)ctx->n_cus, (n_tickets + 15) / 16);
+        a.ticket = (unsigned int*)ctx->ticket.p;
+        a.ticket_base = ctx->ticket_base;
+        ctx->ticket_base += n_tickets + (unsigned int)grid * (LDS_BLOCK / 64);
+        hipLaunchKernelGGL(k_render_bvh_lds, dim3(grid), dim3(LDS_BLOCK), ctx->lds_bytes, st, a);
+    } else if (use_bvh)
         hipLaunchKernelGGL(k_render_bvh, dim3(n_blocks), dim3(64 * BLOCK_WAVES),
                            (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4, st, a);
     else

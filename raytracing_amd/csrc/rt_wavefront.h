@@ -109,7 +109,7 @@ __device__ __forceinline__ void wf_run(const GeomBvh& g, uint32_t* head, uint32_
         const int n_idle = __popcll(idle_m);
         if (!exhausted && n_idle >= WF_REFILL) {
             const uint32_t k = wf_draw(head, total, cur == NONE, &exhausted);
-            if (k != NONE && job.setup(k)) cur = 0u, sp = 0, lk = 0;
+            if (k != NONE && job.setup(k)) cur = 0u, sp = 0, lk = 0;  // node 0 = root holder
             continue;
         }
         if (n_idle == 64) {
@@ -120,8 +120,7 @@ __device__ __forceinline__ void wf_run(const GeomBvh& g, uint32_t* head, uint32_
         const int n_leaf = __popcll(__ballot(at_leaf));
         if (64 - n_idle - n_leaf >= n_leaf) {
             if (!(cur & LEAF)) {  // node step (NONE has the leaf bit)
-                const float4* nd = g.bvh + 4 * (size_t)cur;
-                const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+                const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2), q3 = g.bvh_node(cur, 3);
                 const float th = job.t_hi();
                 float e0, e1;
                 const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
