@@ -6,9 +6,10 @@
 
 Workload (BASELINE.json configs[1]): TeapotScene -- assets/teapot via OBJImportHelper + RTree over
 the mirror floor with TestScene1's six lights -- 1920x1080, shadows + 1 reflection bounce.
-A step renders world-size frames of a camera orbit; every frame is cut into 16-row bands dealt
-round-robin to the ranks, rendered into HBM and assembled on every rank with one RCCL
-all-gather per frame.  Per-GPU work per step is therefore one frame's worth at any N ("weak").
+A step renders world-size frames of a camera orbit; every frame is cut into 8-row bands dealt
+round-robin to the ranks, rendered into HBM, and the whole batch is assembled on every rank with ONE
+RCCL all-gather per step (double buffered, so the exchange of step s-1 overlaps the render of step
+s).  Per-GPU work per step is therefore one frame's worth at any N ("weak").
 Rays are counted by the reference's rule (primary + executed mirror bounces + shadow rays) with
 the reference-order kernel outside the timed region; the count is identical to the oracle's.
 
@@ -30,7 +31,7 @@ sys.path.insert(0, ROOT)
 KERNEL_OF = {1: "k_render<false> (wave-cooperative walk)", 2: "k_render_bvh (per-lane BVH, LDS stacks)",
              3: "k_wf_closest + k_wf_any + k_wf_shade per bounce (wavefront pipeline, whole frame)"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BAND_ROWS = 16
+BAND_ROWS = 8  # one 8x8 tile row per band: finest interleave of sky / mesh / floor rows over the ranks
 
 WORKLOADS = {
     # name: (scene, params, width, height, max_bounces)
@@ -152,6 +153,11 @@ def cpu_baseline(sc, cam, depth, width, height, budget_s=12.0):
                           "sample": f"rows {y0}..{y0 + band - 1}, OpenMP row loop, {dt_all:.1f} s"}}
 
 
+def dbg(*a):
+    if os.environ.get("BENCH_DEBUG"):
+        print(f"[rank {os.environ.get('RANK', '0')}]", *a, file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +166,7 @@ def main():
     ap.add_argument("--workload", default="teapot_1080p_d1", choices=sorted(WORKLOADS))
     ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU workloads")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--verify", action="store_true", help="check the assembled frames against whole-frame renders")
     ap.add_argument("--soup1m", action="store_true", help="include the 1M-triangle soup in the extras")
     args = ap.parse_args()
 
@@ -175,11 +182,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # BENCH_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the N > 1 code path on a one-GPU box
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
+    dbg("process group up")
     scene_name, params, W, H, depth = WORKLOADS[args.workload]
     sc = host.make_scene(scene_name, params=params)
     rt = RayTracer(local_rank)
@@ -189,30 +203,26 @@ def main():
     # rays per step: every frame of the batch, counted by the reference-order kernel (untimed)
     frame_stats = [device_stats(rt, torch, cam, depth) for cam in cams]
     rays_per_step = sum(total_rays(s) for s in frame_stats)
+    dbg("stats done", rays_per_step)
 
-    # ---- timed region: K steps, each = `world` band-sharded frames + one all-gather per frame ----
+    # ---- timed region: K steps, each = `world` band-sharded frames + ONE all-gather for the batch ----
     stream = torch.cuda.current_stream()
-    shards = [P.ShardedFrame(rt, W, H, rank, world, BAND_ROWS) for _ in range(2)]  # double buffered
+    bufs = [P.ShardedFrames(rt, W, H, rank, world, BAND_ROWS, len(cams)) for _ in range(2)]  # double buffered
+
+    step_no = [0]
 
     def step():
-        # frame f renders while the all-gather of frame f-1 is in flight on RCCL's stream
-        pending = [None, None]
+        # step s renders while the all-gather of step s-1 is in flight on RCCL's stream
+        b, other = bufs[step_no[0] % 2], bufs[(step_no[0] + 1) % 2]
+        b.finish()               # this buffer's previous exchange: scanline order, on every rank
+        b.render(cams, depth)
+        other.wait_gather()      # at most one collective in flight (it has overlapped this step's render)
+        b.gather_async()
+        step_no[0] += 1
 
-        def finish(b):
-            if pending[b] is not None:
-                pending[b].wait()          # current stream waits for the gather that used buffer b
-                shards[b].assemble(stream)  # scanline order, on every rank
-                pending[b] = None
-
-        for f, cam in enumerate(cams):
-            b = f % 2
-            finish(b)
-            shards[b].render(cam, depth, stream)
-            if world > 1:
-                pending[b] = dist.all_gather_into_tensor(shards[b].gathered.view(world * shards[b].pr, W, 4),
-                                                         shards[b].local, async_op=True)
-        finish(0)
-        finish(1)
+    def drain():
+        for b in bufs:
+            b.finish()
 
     def fence():
         if world > 1:
@@ -221,15 +231,30 @@ def main():
 
     for _ in range(args.warmup):
         step()
+        dbg("warmup step")
+    drain()
+    dbg("drained")
     fence()
+    dbg("fenced")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(stream)
     for _ in range(args.steps):
         step()
+    drain()
     e1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    dbg("timed region done", elapsed)
+    if args.verify:  # the assembled frames of the last step equal whole-frame renders on this rank
+        last = bufs[(step_no[0] - 1) % 2].frames
+        for f, cam in enumerate(cams):
+            ref = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+            rt.render_device(cam, depth, rgba8=ref.data_ptr(), stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            if not torch.equal(ref, last[f]):
+                raise SystemExit(f"rank {rank}: assembled frame {f} differs from the single-GPU render")
+        dbg("verified", len(cams), "assembled frames")
     kernel_ms = e0.elapsed_time(e1) / (args.steps * len(cams))  # per render launch, on the launch stream
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -258,7 +283,7 @@ def main():
                        "max_bounces": depth, "lights": sc.n_lights, "triangles": len(sc.trianglesData),
                        "frames_per_step": len(cams), "rays_per_step": rays_per_step,
                        "sharding": f"{BAND_ROWS}-row bands round-robin over {world} rank(s), "
-                                   f"RCCL all-gather per frame" if world > 1 else "single GPU, whole frame"},
+                                   f"one RCCL all-gather per step" if world > 1 else "single GPU, whole frame"},
             "ray_breakdown_frame0": {k: st0[k] for k in ("primary_rays", "secondary_rays", "shadow_rays")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

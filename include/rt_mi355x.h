@@ -136,6 +136,11 @@ int rt_padded_rows(int height, int band_rows, int world);
  * elem_size must be 4 or 12.  No counterpart in the reference (single GPU). */
 int rt_unpermute_bands(rt_ctx* ctx, const void* d_gathered, void* d_out, int elem_size, int width,
                        int height, int band_rows, int world, void* stream);
+/* The same for a batch of n_frames frames exchanged with ONE collective: d_gathered holds
+ * [world][n_frames][rt_padded_rows()][W] pixels, d_out receives [n_frames][H][W].  Small frames are
+ * latency bound on xGMI, so hosts that render several frames per step gather them together. */
+int rt_unpermute_frames(rt_ctx* ctx, const void* d_gathered, void* d_out, int elem_size, int width,
+                        int height, int band_rows, int world, int n_frames, void* stream);
 
 /* Introspection for tests and the bench: sizes of the flattened structures on the device. */
 typedef struct rt_scene_info {

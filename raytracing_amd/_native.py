@@ -50,6 +50,7 @@ DEVICE_API = {
     "rt_local_rows": (_I, [_I, _I, _I, _I]),
     "rt_padded_rows": (_I, [_I, _I, _I]),
     "rt_unpermute_bands": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
+    "rt_unpermute_frames": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "rt_get_scene_info": (_I, [_VP, C.POINTER(rt_scene_info)]),
     "rt_check_accel": (_I, [_VP, _I64, _I, _I, C.POINTER(rt_scene_info), C.c_char_p, C.c_size_t]),
     "rt_eval_box": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),

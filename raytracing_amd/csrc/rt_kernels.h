@@ -661,17 +661,19 @@ __global__ void k_gather_planes(const unsigned char* __restrict__ aos, float4* _
 // ------------------------------------------------------------------------------------------
 // multi-GPU: rank-major gathered bands -> scanline order (elem = 4 or 12 bytes, as dwords)
 // ------------------------------------------------------------------------------------------
+// gathered: [world][n_frames][padded_rows][width] elements, out: [n_frames][height][width]
 __global__ void k_unpermute(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ out, int dwords,
-                            int width, int height, int band_rows, int world, int padded_rows) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // dword index in the output frame
+                            int width, int height, int band_rows, int world, int padded_rows, int n_frames) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // dword index in the output frames
     const size_t row_dw = (size_t)width * dwords;
-    if (i >= row_dw * height) return;
-    const int y = (int)(i / row_dw);
+    if (i >= row_dw * height * n_frames) return;
+    const size_t row = i / row_dw;
+    const int f = (int)(row / height), y = (int)(row % height);
     const size_t in_row = i % row_dw;
     const int band = y / band_rows;
     const int owner = band % world;
     const int r = (band / world) * band_rows + y % band_rows;  // local row on the owner
-    out[i] = gathered[((size_t)owner * padded_rows + r) * row_dw + in_row];
+    out[i] = gathered[(((size_t)owner * n_frames + f) * padded_rows + r) * row_dw + in_row];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -535,20 +535,26 @@ int rt_render(rt_ctx* ctx, const float camera[14], int max_bounces, float* rgb, 
     return RT_OK;
 }
 
-int rt_unpermute_bands(rt_ctx* ctx, const void* d_gathered, void* d_out, int elem_size, int width, int height,
-                       int band_rows, int world, void* stream) {
+int rt_unpermute_frames(rt_ctx* ctx, const void* d_gathered, void* d_out, int elem_size, int width, int height,
+                        int band_rows, int world, int n_frames, void* stream) {
     if (!ctx || !d_gathered || !d_out) return RT_ERR_INVALID_ARGUMENT;
-    if ((elem_size != 4 && elem_size != 12) || width <= 0 || height <= 0 || band_rows <= 0 || world <= 0)
+    if ((elem_size != 4 && elem_size != 12) || width <= 0 || height <= 0 || band_rows <= 0 || world <= 0 || n_frames <= 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "elem_size must be 4 or 12; sizes must be positive");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int dwords = elem_size / 4;
-    const size_t total = (size_t)width * height * dwords;
+    const size_t total = (size_t)width * height * dwords * n_frames;
+    if ((total + 255) / 256 > 0x7FFFFFFFull) return fail(ctx, RT_ERR_TOO_LARGE, "too many pixels for one un-permute launch");
     const int padded = rt_padded_rows(height, band_rows, world);
     hipLaunchKernelGGL(k_unpermute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint32_t*)d_gathered, (uint32_t*)d_out, dwords, width, height, band_rows, world,
-                       padded);
+                       padded, n_frames);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
+}
+
+int rt_unpermute_bands(rt_ctx* ctx, const void* d_gathered, void* d_out, int elem_size, int width, int height,
+                       int band_rows, int world, void* stream) {
+    return rt_unpermute_frames(ctx, d_gathered, d_out, elem_size, width, height, band_rows, world, 1, stream);
 }
 
 // ---- per-function evaluators -------------------------------------------------------------

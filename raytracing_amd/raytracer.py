@@ -150,6 +150,11 @@ class RayTracer:
         self._check(self._lib.rt_unpermute_bands(self._ctx, vp(gathered), vp(out), int(elem_size), int(width),
                                                  int(height), int(band_rows), int(world), vp(stream)))
 
+    def unpermute_frames(self, gathered, out, elem_size, width, height, band_rows, world, n_frames, stream=0):
+        vp = lambda v: C.c_void_p(int(v)) if v else None  # noqa: E731
+        self._check(self._lib.rt_unpermute_frames(self._ctx, vp(gathered), vp(out), int(elem_size), int(width),
+                                                  int(height), int(band_rows), int(world), int(n_frames), vp(stream)))
+
     def local_rows(self, height, band_rows, rank, world):
         return self._lib.rt_local_rows(height, band_rows, rank, world)
 

@@ -56,9 +56,20 @@ def _worker(rank, world, port, w, h, band, depth, q):
             local[lr] = torch.from_numpy(r["rgba8"][0])
         gathered = P.all_gather_bands(local, world)
         frame = P.assemble_rows(gathered, h, band, world)
+        # the batched form bench.py uses: two frames (the second without bounces) in ONE collective
+        local2 = torch.zeros((2, pr, w, 4), dtype=torch.uint8)
+        local2[0] = local
+        for lr, y in enumerate(rows):
+            r = oracle_render(sc, cam, 0, threads=1, region=(0, int(y), w, int(y) + 1), want=("rgba8",))
+            local2[1, lr] = torch.from_numpy(r["rgba8"][0])
+        g2 = torch.empty((world, 2, pr, w, 4), dtype=torch.uint8)
+        dist.all_gather_into_tensor(g2.view(world * 2 * pr, w, 4), local2.view(2 * pr, w, 4))
+        frames = P.assemble_frames(g2, h, band, world)
         if rank == 0:
             full = oracle_render(sc, cam, depth, threads=2, want=("rgba8",))["rgba8"]
-            q.put(bool(np.array_equal(frame.numpy(), full)))
+            full0 = oracle_render(sc, cam, 0, threads=2, want=("rgba8",))["rgba8"]
+            q.put(bool(np.array_equal(frame.numpy(), full)) and bool(np.array_equal(frames[0].numpy(), full))
+                  and bool(np.array_equal(frames[1].numpy(), full0)))
         dist.barrier()
     finally:
         dist.destroy_process_group()

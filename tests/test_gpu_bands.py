@@ -45,6 +45,32 @@ def test_bands_assemble_to_the_full_frame(w, h, band, world, rt, scene_of, trave
         assert (fid[r][P.local_rows(h, band, r, world):] == -7).all()
 
 
+def test_batched_frames_unpermute(rt, scene_of):
+    """bench.py's exchange: several frames' bands gathered together, one un-permute launch."""
+    sc = scene_of("TeapotScene")
+    w, h, band, world, F = 96, 54, 8, 4, 3
+    cams = [sc.camera_for(w, h)] + [None] * (F - 1)
+    from raytracing_amd import host
+    for f in range(1, F):
+        cams[f] = host.camera_orbit(f * 20, 256, w, h)
+    rt.SendPrimitivesToShader(sc)
+    dev = torch.device("cuda", 0)
+    pr = P.padded_rows(h, band, world)
+    gathered = torch.zeros((world, F, pr, w, 4), dtype=torch.uint8, device=dev)
+    full = torch.zeros((F, h, w, 4), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for f, cam in enumerate(cams):
+        rt.render_device(cam, 1, rgba8=full[f].data_ptr(), stream=st)
+        for r in range(world):
+            rt.render_device(cam, 1, rgba8=gathered[r, f].data_ptr(), band_rows=band, rank=r, world=world, stream=st)
+    out = torch.empty_like(full)
+    rt.unpermute_frames(gathered.data_ptr(), out.data_ptr(), 4, w, h, band, world, F, stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(out, full)
+    assert torch.equal(P.assemble_frames(gathered, h, band, world), full)
+    assert len(torch.unique(full[1].view(-1, 4), dim=0)) > 50   # a real picture, not a blank frame
+
+
 def test_unpermute_float3(rt):
     w, h, band, world = 50, 37, 8, 3
     pr = P.padded_rows(h, band, world)
