@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 KERNEL_OF = {1: "k_render<false> (wave-cooperative walk)", 2: "k_render_bvh (per-lane BVH, LDS stacks)",
              3: "k_wf_closest + k_wf_any + k_wf_shade per bounce (wavefront pipeline, whole frame)"}
+FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BAND_ROWS = 8  # one 8x8 tile row per band: finest interleave of sky / mesh / floor rows over the ranks
 
@@ -40,6 +41,7 @@ WORKLOADS = {
     "testscene1_720p_d10": ("TestScene1", None, 1280, 720, 10),
     "teapottable_1080p_d8": ("TeapotTable", None, 1920, 1080, 8),
     "soup1m_4k_d4": ("Soup", [1_000_000, 10_000, 8], 3840, 2160, 4),
+    "soup1m_8k_d4": ("Soup", [1_000_000, 10_000, 8], 7680, 4320, 4),
     "soup100k_1080p_d4": ("Soup", [100_000, 1_000, 8], 1920, 1080, 4),
 }
 
@@ -49,6 +51,13 @@ def algorithmic_bytes(stats, width, height):
     return (32 * stats["node_tests"] + 4 * stats["refs_read"] + 16 * stats["sphere_tests"] +
             64 * stats["triangle_tests"] + 32 * stats["plane_tests"] + 32 * stats["material_fetches"] +
             4 * width * height)
+
+
+def algorithmic_flops(stats):
+    """flops of the reference algorithm per frame (27 per box test, 30 per sphere, 75 per
+    triangle, 8 per plane test) -- the VALU-side figure for cache-resident scenes."""
+    return (27 * stats["node_tests"] + 30 * stats["sphere_tests"] + 75 * stats["triangle_tests"] +
+            8 * stats["plane_tests"])
 
 
 def total_rays(stats):
@@ -269,6 +278,8 @@ def main():
         # one launch renders 1/world of a frame; algorithmic bytes scale the same way
         alg_bytes = sum(algorithmic_bytes(s, W, H) for s in frame_stats) / len(frame_stats) / world
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        alg_flops = sum(algorithmic_flops(s) for s in frame_stats) / len(frame_stats) / world
+        valu_tf = alg_flops / (kernel_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and os.path.exists(tpath):
@@ -289,8 +300,15 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": KERNEL_OF.get(rt.scene_info()["traversal"], "?"), "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "algorithmic bytes of the REFERENCE algorithm (SURVEY 8d); this scene is "
-                                 "L2-resident, so the binding limit is VALU issue, not HBM"},
+                         "note": "algorithmic bytes of the REFERENCE algorithm (SURVEY 8d: every candidate "
+                                 "tested, no distance cull); the kernel culls and orders, so it is credited with "
+                                 "more bytes than it moves (frac can exceed 1) -- `traffic` is what HBM saw.  "
+                                 "This scene is L2-resident: the binding limit is VALU issue, see `valu`",
+                         "valu": {"algorithmic_flops_per_launch": int(alg_flops),
+                                  "achieved_tflops": round(valu_tf, 2), "peak_tflops": FP32_VECTOR_PEAK_TF,
+                                  "frac": round(valu_tf / FP32_VECTOR_PEAK_TF, 4),
+                                  "note": "peak counts FMA as 2 flops; the canonical arithmetic forbids "
+                                          "contraction, so half of it is reachable"}},
         }
 
     # ---- N = 1 only: extra workloads and the CPU baseline (outside the contract's timed region) ----

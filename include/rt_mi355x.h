@@ -61,7 +61,7 @@ enum {
     RT_RENDER_DEFAULT = 0,
     RT_RENDER_REFERENCE_ORDER = 1, /* run the exhaustive kernel that follows the reference's
                                       candidate rules literally (used for rt_stats; slower) */
-    RT_RENDER_GLOBAL_MEMORY = 2    /* never use the LDS-resident kernel, even if the scene fits LDS */
+    RT_RENDER_GLOBAL_MEMORY = 2    /* never use the LDS-resident kernel, even if RT_OPTION_USE_LDS is set */
 };
 
 /* Replaces GL.CreateProgram + shader load/compile/link, RayTracer.cs:49-62.
@@ -73,9 +73,9 @@ const char* rt_last_error(const rt_ctx* ctx);
 
 /* Tuning knobs of a context (no counterpart in the reference).  Results never depend on them. */
 enum {
-    RT_OPTION_USE_LDS = 1,   /* 1: scenes whose flattened geometry fits the CU's 160 KB LDS are rendered by
-                                the LDS-resident persistent kernel; 0 (default): geometry stays in HBM/L2
-                                and is read through the scalar cache (measured faster) */
+    RT_OPTION_USE_LDS = 1,   /* 1: small scenes (triangle/sphere slots + BVH nodes + per-lane stacks within the
+                                CU's 160 KB LDS) are rendered by the LDS-resident persistent form of the BVH
+                                kernel; 0 (default): geometry stays in HBM/L2 (measured faster) */
     RT_OPTION_SUPERTILE = 2, /* edge, in 8x8-pixel tiles, of the super-tiles dealt round-robin to the
                                 XCDs by the global-memory kernels (default 8, 1..64) */
     RT_OPTION_TRAVERSAL = 3  /* RT_TRAVERSAL_*: which fast kernel renders (default AUTO: by scene size) */
