@@ -1,0 +1,73 @@
+"""Host-side "next" rows: framebuffer dump and debug overlay data."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from raytracing_amd import debug, image
+
+
+def _read_png(path):
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(b):
+        n, tag = struct.unpack(">I", b[pos:pos + 4])[0], b[pos + 4:pos + 8]
+        data = b[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        if tag == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", data[:10])
+            assert (depth, ctype) == (8, 2)
+        if tag == b"IDAT":
+            idat += data
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+def test_png_and_ppm_are_top_down(tmp_path):
+    g = np.random.default_rng(1)
+    fb = g.integers(0, 256, (7, 5, 4), dtype=np.uint8)     # library order: row 0 = bottom row
+    image.write_png(tmp_path / "a.png", fb)
+    assert np.array_equal(_read_png(tmp_path / "a.png"), fb[::-1, :, :3])
+    image.write_ppm(tmp_path / "a.ppm", fb)
+    b = open(tmp_path / "a.ppm", "rb").read()
+    assert b.startswith(b"P6\n5 7\n255\n")
+    assert np.array_equal(np.frombuffer(b[len(b"P6\n5 7\n255\n"):], np.uint8).reshape(7, 5, 3), fb[::-1, :, :3])
+    with pytest.raises(ValueError):
+        image.write_png(tmp_path / "b.png", fb.astype(np.float32))
+
+
+def test_quantise_rule():
+    rgb = np.array([[[-1.0, 0.0, 0.5], [1.0, 2.0, np.nan], [0.5 / 255, 1.5 / 255, 2.5 / 255]]], np.float32)
+    q = image.quantise(rgb)
+    assert q[0, 0].tolist() == [0, 0, 128, 255] and q[0, 1].tolist() == [255, 255, 0, 255]
+    assert q[0, 2, :3].tolist() == [0, 2, 2]      # ties to even, as the device's rintf
+
+
+def test_rtree_boxes_reads_the_serialised_tree(scene_of):
+    sc = scene_of("TestScene1")
+    boxes = debug.rtree_boxes(sc.AccelerationStructureData)
+    leaves = boxes[boxes["is_leaf"]]
+    assert leaves["count"].sum() == len(sc.spheresData) + len(sc.trianglesData)
+    assert (boxes[~boxes["is_leaf"]]["count"] == 2).all()          # the tree is effectively binary
+    assert boxes[0]["depth"] == 0 and boxes["depth"].max() >= 5
+    assert (boxes["lo"] >= boxes[0]["lo"]).all() and (boxes["hi"] <= boxes[0]["hi"]).all()
+    assert len(debug.rtree_boxes(np.zeros(0, np.float32))) == 0
+
+
+@pytest.mark.gpu
+def test_sample_rays(rt, scene_of):
+    sc = scene_of("TestScene1")
+    rt.SendPrimitivesToShader(sc)
+    rt.PrepareRenderOpenGL(sc.camera_for(1280, 720))
+    r = debug.sample_rays(rt)
+    assert r["directions"].shape == (15, 3) and len(r["primary_id"]) == 15
+    assert np.allclose(np.linalg.norm(r["directions"], axis=1), 1, atol=1e-6)
+    assert (r["primary_id"] >= 0).any()
+    for d, i in zip(r["directions"], r["primary_id"]):
+        t = debug.hit_distance(sc, r["origin"], d, int(i))
+        assert t > 0
+    assert rt.cameraData[12] == 1280          # the caller's camera is restored
