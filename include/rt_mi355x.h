@@ -121,7 +121,11 @@ int rt_render(rt_ctx* ctx, const float camera[14], int max_bounces, float* rgb, 
  * DEVICE pointers to compact arrays of rt_local_rows() * W pixels (NULL = not wanted).
  * d_bounces: int32 bounce count per pixel.  d_stats: device pointer to one rt_stats that is
  * ACCUMULATED into (caller zeroes it), only honoured with RT_RENDER_REFERENCE_ORDER.
- * stream: a hipStream_t (NULL = default stream); the call is asynchronous on it. */
+ * stream: a hipStream_t (NULL = default stream); the call is asynchronous on it.  One context may
+ * render on several streams at once; renders of large scenes (RT_TRAVERSAL_WAVEFRONT) keep their ray
+ * queues in per-context device buffers (allocated or grown inside this call on first use of a frame
+ * size: 80 B per local pixel + one byte per shadow ray) and are therefore run one after the other on
+ * the device, whichever streams they were issued on. */
 int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int flags, int band_rows,
                      int rank, int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id,
                      int32_t* d_final_id, int32_t* d_bounces, rt_stats* d_stats, void* stream);

@@ -50,6 +50,11 @@ struct rt_ctx {
     int wf_min_nodes = 100000; // auto: scenes with at least this many flat nodes take the wavefront pipeline
     int wf_max_bounces = 64;   // beyond this the per-bounce launches stop paying: megakernel instead
     int wf_waves_per_cu = 24;  // persistent waves of the two trace stages
+    // The wavefront path state and the LDS kernel's ticket counter are per context: renders that use
+    // them are chained on the device (each waits for the previous one's event), whatever streams the
+    // caller launches on.  The megakernels keep no per-context state and overlap freely.
+    hipEvent_t chain_done = nullptr;
+    bool chain_pending = false;
     // frame buffers of rt_render (grow only)
     DevBuf fb_rgb, fb_rgba8, fb_pid, fb_fid, fb_stats;
     // scratch of the evaluators
@@ -119,6 +124,18 @@ int camera_size(const float* cam, int* w, int* h) {
     return RT_OK;
 }
 
+// Order a render that uses per-context device state behind the previous such render (see rt_ctx).
+int chain_begin(rt_ctx* ctx, hipStream_t st) {
+    if (!ctx->chain_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chain_done, hipEventDisableTiming));
+    if (ctx->chain_pending) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->chain_done, 0));
+    return RT_OK;
+}
+int chain_end(rt_ctx* ctx, hipStream_t st) {
+    HIP_TRY(ctx, hipEventRecord(ctx->chain_done, st));
+    ctx->chain_pending = true;
+    return RT_OK;
+}
+
 // The staged pipeline of rt_wavefront.h: per bounce one closest-hit stage, one shadow stage, one
 // shading stage, all on `st`; list sizes stay on the device (persistent / grid-stride kernels read
 // them), so the host never synchronises.
@@ -151,6 +168,7 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st) {
     a.list[0] = (uint32_t*)ctx->wf_list0.p, a.list[1] = (uint32_t*)ctx->wf_list1.p;
     a.blocked = (unsigned char*)ctx->wf_blocked.p;
     a.counters = (uint32_t*)ctx->wf_counters.p;
+    if ((rc = chain_begin(ctx, st))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, n_counters * 4, st));
     const int trace_grid = ctx->n_cus * ctx->wf_waves_per_cu;
     const size_t lds = (size_t)64 * std::max(a.scene.bvh_levels, 1) * 4;
@@ -164,7 +182,7 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st) {
         hipLaunchKernelGGL(k_wf_shade, dim3(shade_grid), dim3(256), 0, st, a);
     }
     HIP_TRY(ctx, hipGetLastError());
-    return RT_OK;
+    return chain_end(ctx, st);
 }
 
 }  // namespace
@@ -234,6 +252,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    if (ctx->chain_done) (void)hipEventDestroy(ctx->chain_done);
     DevBuf* wf[] = {&ctx->wf_org,   &ctx->wf_dir,   &ctx->wf_mult,    &ctx->wf_final,
                     &ctx->wf_list0, &ctx->wf_list1, &ctx->wf_blocked, &ctx->wf_counters};
     for (DevBuf* b : wf) release(*b);
@@ -493,7 +512,10 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
         a.ticket = (unsigned int*)ctx->ticket.p;
         a.ticket_base = ctx->ticket_base;
         ctx->ticket_base += n_tickets + (unsigned int)grid * (LDS_BLOCK / 64);
+        int rc = chain_begin(ctx, st);  // the ticket arithmetic assumes launches run in issue order
+        if (rc != RT_OK) return rc;
         hipLaunchKernelGGL(k_render_bvh_lds, dim3(grid), dim3(LDS_BLOCK), ctx->lds_bytes, st, a);
+        if ((rc = chain_end(ctx, st)) != RT_OK) return rc;
     } else if (use_bvh)
         hipLaunchKernelGGL(k_render_bvh, dim3(n_blocks), dim3(64 * BLOCK_WAVES),
                            (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4, st, a);

@@ -156,3 +156,32 @@ def test_all_traversals_agree_at_full_size_soup1m(rt_mode, scene_of):
     ref = oracle_render(sc, cam, 4, threads=16, region=(x0, y0, x1, y1))
     crop = {k: v[y0:y1, x0:x1] for k, v in slow.items() if k in want}
     assert_frame_matches(crop, ref, "soup1m crop")
+
+
+def test_wavefront_renders_issued_on_two_streams_do_not_mix(rt_mode, scene_of):
+    """The wavefront pipeline keeps its ray queues in per-context buffers; renders issued on different
+    streams must be chained on the device, not interleaved (bench.py renders a step's frames over
+    several streams)."""
+    import torch
+    from raytracing_amd import host
+    rt = rt_mode
+    sc = scene_of("Soup", [8000, 80, 8])
+    rt.SendPrimitivesToShader(sc)
+    w, h = 320, 180
+    cams = [sc.camera_for(w, h), host.camera_pack([30, 25, -70], [-0.3, -0.2, 1], [1, 0, 0.3], 1.0, 1.6, 0.9, w, h)]
+    rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_WAVEFRONT)
+    main = torch.cuda.current_stream()
+    ref = []
+    for cam in cams:
+        out = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+        rt.render_device(cam, 4, rgba8=out.data_ptr(), stream=main.cuda_stream)
+        torch.cuda.synchronize()
+        ref.append(out)
+    assert not torch.equal(ref[0], ref[1])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(6)]
+    for k, out in enumerate(outs):       # six renders back to back, alternating streams and cameras
+        rt.render_device(cams[k % 2], 4, rgba8=out.data_ptr(), stream=streams[k % 2].cuda_stream)
+    torch.cuda.synchronize()
+    for k, out in enumerate(outs):
+        assert torch.equal(out, ref[k % 2]), f"render {k}"
