@@ -66,7 +66,10 @@ __device__ __forceinline__ const uint32_t* wf_list_in(const WfArgs& a) { return 
 __device__ __forceinline__ uint32_t* wf_list_out(const WfArgs& a) { return (a.iter & 1) ? a.list[0] : a.list[1]; }
 __device__ __forceinline__ uint32_t wf_active_count(const WfArgs& a) { return a.iter == 0 ? a.n0 : a.counters[4 * a.iter]; }
 
-constexpr int WF_REFILL = 8;  // idle lanes that trigger a refill (wave runs >= 56/64 busy until the list ends)
+#ifndef RT_WF_REFILL
+#define RT_WF_REFILL 24
+#endif
+constexpr int WF_REFILL = RT_WF_REFILL;  // idle lanes that trigger a refill (measured: 8 -> 182 ms, 16 -> 150, 24 -> 147, 48 -> 180 on Soup1M 4K)
 
 // Draw work items for the idle lanes of the wave: one atomic per call.  Returns this lane's item or
 // 0xFFFFFFFF; *exhausted becomes true (wave-uniform) once the list has been handed out completely.
