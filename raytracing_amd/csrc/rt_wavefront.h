@@ -235,7 +235,10 @@ struct WfClosestJob {
     }
 };
 
-__global__ __launch_bounds__(64) void k_wf_closest(const WfArgs a) {
+#ifndef RT_WF_WAVES_PER_EU
+#define RT_WF_WAVES_PER_EU 6  // 80 VGPRs (20 B of spill): Soup1M 4K 148.8 -> 140.3 ms; 8 waves (64 VGPRs) spill 88 B: 375 ms
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_PER_EU, 8))) void k_wf_closest(const WfArgs a) {
     const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
     WfClosestJob job{a, g, a.iter == 0 ? 0.0f : RT_EPSILON};
     wf_run(g, a.counters + 4 * a.iter + 1, wf_active_count(a), job);
@@ -333,7 +336,7 @@ struct WfAnyJob {
     }
 };
 
-__global__ __launch_bounds__(64) void k_wf_any(const WfArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_PER_EU, 8))) void k_wf_any(const WfArgs a) {
     const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
     const uint32_t n_active = wf_active_count(a);
     WfAnyJob job{a, g, n_active, RT_EPSILON};
