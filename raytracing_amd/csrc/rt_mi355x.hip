@@ -369,7 +369,8 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     }
 
     // distance cull precondition: boxes nested, every primitive inside its leaf box (within a slack
-    // far below the cull's pad); otherwise the kernels never cull
+    // far below the cull's pad), triangle normals perpendicular to their triangles; otherwise the
+    // kernels never cull
     bool contained = flat.nested;
     if (contained) {
         const float slack = std::fmax(s.extent[0], std::fmax(s.extent[1], s.extent[2])) * (1.0f / 4096.0f);
@@ -388,6 +389,19 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
                             const float x = rec[4 * v + c];
                             if (!(x >= lo[c] && x <= hi[c])) contained = false;
                         }
+                    // the stored normal must be the triangle's: IntersectTriangle intersects the plane through
+                    // A with THAT normal, and the cull's proof needs the hit point on the triangle.  Measured
+                    // as the distance of B and C from that plane, allowed up to 1/8 of the cull's pad (the
+                    // reference's own sliver triangles reach 3e-3 rad, 0.003 units).  A NaN normal (zero-area
+                    // triangle, 32 of them in the teapot) never produces a hit and is fine.
+                    const float* n = rec + 12;
+                    const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+                    for (int v = 1; v < 3 && nn == nn; v++) {
+                        const double off = std::fabs(((double)rec[4 * v] - rec[0]) * n[0] +
+                                                     ((double)rec[4 * v + 1] - rec[1]) * n[1] +
+                                                     ((double)rec[4 * v + 2] - rec[2]) * n[2]);
+                        if (!(nn > 0) || !(off <= 4.0 * slack * nn)) contained = false;
+                    }
                 } else {
                     const float* rec = (const float*)(Sp + (size_t)flat.sphere_slot_id[first + k] * 48);
                     for (int c = 0; c < 3; c++)

@@ -185,3 +185,23 @@ def test_wavefront_renders_issued_on_two_streams_do_not_mix(rt_mode, scene_of):
     torch.cuda.synchronize()
     for k, out in enumerate(outs):
         assert torch.equal(out, ref[k % 2]), f"render {k}"
+
+
+def test_normals_that_are_not_the_triangles_switch_the_cull_off(rt_mode, scene_of):
+    """IntersectTriangle intersects the plane through A with the STORED normal, whatever it is.  The
+    distance cull assumes hit points lie on the triangle, so a scene with skewed normals must be rendered
+    without it (flags lose RT_SCENE_CULL) and still match the oracle in every traversal."""
+    rt = rt_mode
+    sc = scene_of("TeapotScene")
+    tri = sc.trianglesData.copy()
+    g = np.random.default_rng(5)
+    n = tri["Normal"] + g.normal(scale=0.4, size=tri["Normal"].shape).astype(np.float32)
+    tri["Normal"] = n / np.linalg.norm(n, axis=1, keepdims=True)
+    skew = Scene(sc.spheresData, sc.planesData, tri, sc.AccelerationStructureData, sc.lightsData, sc.cameraData)
+    cam = skew.camera_for(160, 90)
+    ref = oracle_render(skew, cam, 1)
+    for mode, label in MODES:
+        rt.set_option(rt.OPTION_TRAVERSAL, mode)
+        out = _render(rt, skew, cam, 1)
+        assert rt.scene_info()["flags"] == 1      # nested, but no cull
+        assert_frame_matches(out, ref, "skewed normals " + label)
