@@ -512,7 +512,11 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
     a.ticket_base = 0;
     if (a.tiles_y == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int trav = pick_traversal(ctx, a.scene, max_bounces);
+    int trav = pick_traversal(ctx, a.scene, max_bounces);
+    // the staged pipeline indexes (pixel, light) work items with 32 bits: beyond that, the megakernel
+    if (trav == RT_TRAVERSAL_WAVEFRONT &&
+        (size_t)((w + 7) / 8) * ((a.local_rows + 7) / 8) * 64 * (size_t)std::max(a.scene.lights_len / 6, 1) >= 0xFFFFFFF0ull)
+        trav = RT_TRAVERSAL_BVH;
     const bool use_wf = trav == RT_TRAVERSAL_WAVEFRONT, use_bvh = trav == RT_TRAVERSAL_BVH;
     if (flags & RT_RENDER_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);

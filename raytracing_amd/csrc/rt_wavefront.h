@@ -6,9 +6,9 @@
 // (tools/diag_steps.py).  Here the path is cut at every ray, and the rays of ALL pixels are regrouped:
 //
 //   for iteration i = 0 .. max_bounces            (i = number of mirror bounces already taken)
-//     k_wf_closest  persistent waves; every lane draws the next ray of the active list when its own
-//                   ray is finished (ballot + mbcnt compaction of the idle lanes, one atomic per
-//                   refill), so the traversal loop always runs with >= 56 of 64 lanes busy
+//     k_wf_closest  persistent waves; lanes whose ray is finished draw the next rays of the active list
+//                   together (ballot + mbcnt compaction of the idle lanes, one atomic per refill of
+//                   WF_REFILL lanes), so the traversal loop keeps >= 40 of 64 lanes supplied with rays
 //     k_wf_any      the same for the shadow rays: work item (active path j, light l)
 //     k_wf_shade    one thread per active path: the reference's shading code for this bounce
 //                   (raytracer_fs.glsl:334-381 or 384-424), appends mirror paths to the next list
