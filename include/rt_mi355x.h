@@ -78,7 +78,12 @@ enum {
                                 kernel; 0 (default): geometry stays in HBM/L2 (measured faster) */
     RT_OPTION_SUPERTILE = 2, /* edge, in 8x8-pixel tiles, of the super-tiles dealt round-robin to the
                                 XCDs by the global-memory kernels (default 8, 1..64) */
-    RT_OPTION_TRAVERSAL = 3  /* RT_TRAVERSAL_*: which fast kernel renders (default AUTO: by scene size) */
+    RT_OPTION_TRAVERSAL = 3, /* RT_TRAVERSAL_*: which fast kernel renders (default AUTO: by scene size) */
+    RT_OPTION_TIGHT_TREE = 4, /* 1 (default): uploads of large scenes also build a per-primitive tree that the
+                                staged pipeline walks as a filter in front of the reference's leaf-box rule
+                                (64 B per primitive, ~1 s of host time per million); 0: neither built nor used */
+    RT_OPTION_WAVEFRONT_MIN_NODES = 5 /* "large scene" threshold in flattened node records (default 30000):
+                                from it on AUTO picks RT_TRAVERSAL_WAVEFRONT and uploads build the tight tree */
 };
 enum {
     RT_TRAVERSAL_AUTO = 0,
@@ -158,7 +163,8 @@ typedef struct rt_scene_info {
     int64_t bvh_levels;     /* LDS stack entries per lane the BVH kernel reserves      */
     int64_t flags;          /* RT_SCENE_*                                              */
     int64_t traversal;      /* RT_TRAVERSAL_* a default render (max_bounces 10) uses   */
-    int64_t reserved[2];
+    int64_t tight_nodes;    /* 64-byte nodes of the per-primitive tree (0 = not built) */
+    int64_t tight_levels;   /* its depth                                               */
 } rt_scene_info;
 enum {
     RT_SCENE_NESTED = 1,    /* every box lies inside its parent's (true for every RTree.cs tree) */

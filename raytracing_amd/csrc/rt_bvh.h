@@ -22,6 +22,7 @@
 // as child 0 and an empty leaf as child 1, so a traversal always starts with `cur = 0`.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <vector>
 
@@ -172,12 +173,38 @@ struct Builder {
 
 }  // namespace detail
 
+namespace detail {
+// Builds items[0, split) and items[split, n) as the two children of the root holder (node 0), so a
+// traversal always starts with `cur = 0`.  split == n: one tree, the second child is an empty leaf.
+inline void build_items(std::vector<Item>& items, size_t split, Bvh* out) {
+    out->nodes.clear();
+    out->levels = 0;
+    out->leaves = (int64_t)items.size();
+    if (items.empty()) return;
+    out->nodes.reserve(items.size() + 1);
+    out->nodes.emplace_back();  // node 0: root holder
+    out->levels = 1;
+    Builder bld{items, *out};
+    Box box[2];
+    uint32_t ref[2] = {LEAF, LEAF};  // empty leaf (count 0): harmless even if its box were accepted
+    for (int h = 0; h < 2; h++) {
+        const size_t b = h ? split : 0, e = h ? items.size() : split;
+        box[h].reset();  // inverted: rejected by any finite ray
+        if (e > b) ref[h] = bld.build(b, e, 1, &box[h]);
+    }
+    Node& h = out->nodes[0];
+    for (int k = 0; k < 3; k++) {
+        h.lo0[k] = box[0].lo[k], h.hi0[k] = box[0].hi[k];
+        h.lo1[k] = box[1].lo[k], h.hi1[k] = box[1].hi[k];
+    }
+    h.ref0 = ref[0], h.ref1 = ref[1];
+    h.pad0 = h.pad1 = 0;
+}
+}  // namespace detail
+
 // Re-tree the leaves of a flattened reference tree (flat.nested must hold).  Leaves without
 // primitives are dropped (they have no candidates).  An empty tree yields no nodes.
 inline void build(const rtf::Flat& flat, Bvh* out) {
-    out->nodes.clear();
-    out->levels = 0;
-    out->leaves = 0;
     std::vector<detail::Item> items;
     for (const rtf::FlatNode& fn : flat.nodes) {
         const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31;
@@ -189,22 +216,105 @@ inline void build(const rtf::Flat& flat, Bvh* out) {
         it.weight = (float)count;
         items.push_back(it);
     }
-    out->leaves = (int64_t)items.size();
-    if (items.empty()) return;
-    out->nodes.reserve(items.size() + 1);
-    out->nodes.emplace_back();  // node 0: root holder
-    out->levels = 1;
-    detail::Builder bld{items, *out};
-    detail::Box root;
-    const uint32_t ref = bld.build(0, items.size(), 1, &root);
-    Node& h = out->nodes[0];
-    for (int k = 0; k < 3; k++) {
-        h.lo0[k] = root.lo[k], h.hi0[k] = root.hi[k];
-        h.lo1[k] = 3.402823466e+38f, h.hi1[k] = -3.402823466e+38f;  // inverted: rejected by any finite ray
+    detail::build_items(items, items.size(), out);
+}
+
+// ------------------------------------------------------------------------------------------
+// The tight tree: one leaf per primitive slot, boxes fitted to the primitive itself.
+//
+// The reference's leaf boxes are loose for a BVH (an R-tree leaf bounds up to five primitives picked
+// by insertion order): on SoupScene a shadow ray passes the box of ~30 leaves and tests ~64
+// primitives of which ~0.1 are hit.  The tight tree is a FILTER in front of the exact candidate
+// rule, never a replacement for it:
+//
+//   a hit (slot, t) is accepted by the reference
+//        <=>  the primitive test accepts t   AND   the slot's reference leaf box passes the
+//             reference box test (first paragraph of this file; regular rays, nested tree)
+//
+// The traversal of the tight tree finds every slot whose primitive test can accept a t inside the
+// caller's window, runs the reference's primitive test on it, and checks the reference leaf box
+// (slot -> leaf record, *_slot_leaf below) only for hits it is about to accept.  For this the tight
+// boxes must be CONSERVATIVE for the computed hit parameter t_c, i.e. t_c must lie inside the slab
+// interval of every box on the path as the traversal computes it (rt_device.h, SlabHit):
+//
+//   triangle  IntersectTriangle intersects the plane through A with the STORED normal N and accepts
+//             points X whose projection along N falls inside ABC, i.e. X in the triangle A B' C'
+//             (B', C' = B, C projected along N onto that plane; equal to B, C for an exact normal).
+//             The accepted X_c = o + t_c d misses that plane by <= eps(5|A-o| + 3 t_c) and the edges
+//             by a few eps * scale: < 32 eps E with E >= |o_k| + |coordinate| on every axis.  The box
+//             is bbox(A, B', C') grown by pad_tri = 2^-14 E_build (1000 eps E_build).
+//   sphere    the computed root differs from an exact root (or, when rounding created the root, from
+//             the closest approach) by <= sqrt(68 eps)/2 |o-c|, and the closest approach misses the
+//             sphere by at most the same amount: X_c is within 2.0e-3 |o-c| <= 3.5e-3 E of the
+//             sphere.  The box is c +- (r + pad_sphere), pad_sphere = 2^-8 E_build = 3.9e-3 E_build.
+//   slab test errors (fma form, 1/d rounded) are < 6 eps E in space: covered by either pad.
+//
+// E_build is fixed at build time, so only rays with E(o) = max_k(|o_k| + extent_k) <= E_build and a
+// regular direction may use this tree; the others take the leaf-box tree above.  Inner boxes are
+// unions of the padded leaf boxes.
+// ------------------------------------------------------------------------------------------
+struct TightInput {
+    const unsigned char* tris = nullptr;     // TriangleStruct records, 96 B: A|_ B|_ C|_ N|_ ...
+    const unsigned char* spheres = nullptr;  // SphereStruct records, 48 B: center, radius
+    float pad_tri = 0, pad_sphere = 0;
+};
+
+inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, std::vector<int32_t>* tri_slot_leaf,
+                        std::vector<int32_t>* sphere_slot_leaf) {
+    // triangles and spheres get a tree each (the two children of the root holder): the spheres' pad is
+    // 64 x the triangles', mixed in they would inflate every inner box above them
+    std::vector<detail::Item> items, sphere_items;
+    items.reserve(flat.tri_slot_id.size() + flat.sphere_slot_id.size());
+    tri_slot_leaf->assign(flat.tri_slot_id.size(), 0);
+    sphere_slot_leaf->assign(flat.sphere_slot_id.size(), 0);
+    auto down = [](double x) {
+        float f = (float)x;
+        return (double)f > x ? std::nextafterf(f, -INFINITY) : f;
+    };
+    auto up = [](double x) {
+        float f = (float)x;
+        return (double)f < x ? std::nextafterf(f, INFINITY) : f;
+    };
+    for (size_t ni = 0; ni < flat.nodes.size(); ni++) {
+        const rtf::FlatNode& fn = flat.nodes[ni];
+        const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = (int)(fn.meta & 0xFFFFFF);
+        if (kind == rtf::KIND_BRANCH) continue;
+        for (int k = 0; k < count; k++) {
+            const int slot = first + k;
+            detail::Item it;
+            it.weight = 1.0f;
+            it.ref = LEAF | ((uint32_t)kind << 29) | (1u << 24) | (uint32_t)slot;
+            double lo[3], hi[3], pad;
+            if (kind == rtf::KIND_TRI) {
+                (*tri_slot_leaf)[slot] = (int32_t)ni;
+                const float* r = (const float*)(in.tris + (size_t)flat.tri_slot_id[slot] * 96);
+                const double n[3] = {r[12], r[13], r[14]};
+                const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                for (int c = 0; c < 3; c++) lo[c] = hi[c] = r[c];
+                for (int v = 1; v < 3; v++) {
+                    const double e[3] = {(double)r[4 * v] - r[0], (double)r[4 * v + 1] - r[1], (double)r[4 * v + 2] - r[2]};
+                    // projection along N onto the plane through A; a zero or NaN normal never yields a hit
+                    double s = (e[0] * n[0] + e[1] * n[1] + e[2] * n[2]) / nn;
+                    if (!(nn > 0) || !(s == s)) s = 0;
+                    for (int c = 0; c < 3; c++) {
+                        const double x = (double)r[4 * v + c] - s * n[c];
+                        lo[c] = std::min(lo[c], x), hi[c] = std::max(hi[c], x);
+                    }
+                }
+                pad = in.pad_tri;
+            } else {
+                (*sphere_slot_leaf)[slot] = (int32_t)ni;
+                const float* r = (const float*)(in.spheres + (size_t)flat.sphere_slot_id[slot] * 48);
+                for (int c = 0; c < 3; c++) lo[c] = (double)r[c] - r[3], hi[c] = (double)r[c] + r[3];
+                pad = in.pad_sphere;
+            }
+            for (int c = 0; c < 3; c++) it.lo[c] = down(lo[c] - pad), it.hi[c] = up(hi[c] + pad);
+            (kind == rtf::KIND_TRI ? items : sphere_items).push_back(it);
+        }
     }
-    h.ref0 = ref;
-    h.ref1 = LEAF;  // empty leaf (count 0): harmless even if its box were accepted
-    h.pad0 = h.pad1 = 0;
+    const size_t split = items.size();
+    items.insert(items.end(), sphere_items.begin(), sphere_items.end());
+    detail::build_items(items, split, out);
 }
 
 }  // namespace rtb

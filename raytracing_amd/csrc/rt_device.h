@@ -24,6 +24,7 @@ using namespace rtm;
 //   [tri_off, tri_off + 3*n_tri_slots)  3 x float4 per triangle slot: A.xyz B.x | B.yz C.xy | C.z N.xyz
 //   [sph_off, sph_off + n_sph_slots)    1 x float4 per sphere slot: center.xyz radius
 //   [bvh_off, geom_float4s)             4 x float4 per node of the re-treed leaves (rt_bvh.h)
+//   [geom_float4s, ...)                 4 x float4 per node of the tight tree, if built (large scenes)
 // The part from tri_off on is what the LDS-resident kernel copies into a workgroup's LDS.
 struct DevScene {
     const float4* geom;
@@ -44,8 +45,15 @@ struct DevScene {
     // re-treed leaves (rt_bvh.h): 4 x float4 per node, node 0 = root holder; null if not built.
     // They sit at the end of the geometry image (bvh == geom + bvh_off).
     const float4* bvh;
-    int32_t bvh_levels;  // stack entries a traversal can need
+    int32_t bvh_levels;  // stack entries a traversal can need (either tree)
     int32_t bvh_off;
+    // tight per-primitive tree (rt_bvh.h build_tight), stored behind the image as further nodes of
+    // `bvh`: its root holder is node tight_root (0 = not built / not used).  Only rays with
+    // max_k(|o_k| + extent_k) <= tight_e may walk it; *_slot_leaf map a slot to its reference leaf record.
+    uint32_t tight_root;
+    float tight_e;
+    const int32_t* tri_slot_leaf;
+    const int32_t* sphere_slot_leaf;
 };
 
 struct GeomGlobal {
@@ -156,7 +164,8 @@ __device__ __forceinline__ float IntersectTriangle(V3 o, V3 d, V3 A, V3 B, V3 C,
 struct BoxRay {
     V3 o, inv;
     bool sx, sy, sz;
-    V3 padinv;  // distance-cull slack per axis in ray-parameter units (IntersectBoundingBoxCull)
+    V3 padinv;  // distance-cull slack per axis in ray-parameter units (IntersectBoundingBoxCull);
+                // for a ray that walks the tight tree: -o*inv (SlabHit)
 };
 __device__ __forceinline__ BoxRay make_box_ray(V3 o, V3 d) {
     BoxRay r;
@@ -222,6 +231,30 @@ __device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4
     const bool culled = (en > t_hi) | (ef < t_lo);
     if (entry) *entry = en;  // padded entry parameter: orders the two children of a BVH node
     return !(miss_xy | miss_z | culled);
+}
+
+// Slab test of the tight tree (rt_bvh.h build_tight).  NOT the reference's formula and not meant to
+// be: the tight boxes are padded at build time so that this test, with its own rounding (fma form,
+// < 6 eps E in space), never rejects a box whose primitive's test can accept a t in [t_lo, t_hi];
+// exactness is restored by the leaf-box check on accepted hits (rt_wavefront.h).  Requires
+// make_tight_ray; finite everywhere for |1/d| <= 1e30 and coordinates <= 4e6.
+__device__ __forceinline__ bool SlabHit(const BoxRay& r, float4 lo, float4 hi, float t_lo, float t_hi, float* entry) {
+    const float x0 = __builtin_fmaf(lo.x, r.inv.x, r.padinv.x), x1 = __builtin_fmaf(hi.x, r.inv.x, r.padinv.x);
+    const float y0 = __builtin_fmaf(lo.y, r.inv.y, r.padinv.y), y1 = __builtin_fmaf(hi.y, r.inv.y, r.padinv.y);
+    const float z0 = __builtin_fmaf(lo.z, r.inv.z, r.padinv.z), z1 = __builtin_fmaf(hi.z, r.inv.z, r.padinv.z);
+    const float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    const float ef = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    *entry = en;
+    return (en <= ef) & (en <= t_hi) & (ef >= t_lo);
+}
+// May this ray walk the tight tree?  (E_build covers its origin, 1/d small enough that no slab
+// product overflows.)  If so the ray's padinv is replaced by -o*inv.
+__device__ __forceinline__ bool make_tight_ray(BoxRay& r, V3 extent, float tight_e) {
+    const float E = fmaxf(fmaxf(fabsf(r.o.x) + extent.x, fabsf(r.o.y) + extent.y), fabsf(r.o.z) + extent.z);
+    const float big = 1e30f;
+    const bool ok = (E <= tight_e) & (fabsf(r.inv.x) <= big) & (fabsf(r.inv.y) <= big) & (fabsf(r.inv.z) <= big);
+    if (ok) r.padinv = v3(-(r.o.x * r.inv.x), -(r.o.y * r.inv.y), -(r.o.z * r.inv.z));
+    return ok;
 }
 
 // IntersectTriangle for the fast kernels: same arithmetic, but the three edge tests are only

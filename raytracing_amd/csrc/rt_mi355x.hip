@@ -34,6 +34,8 @@ struct rt_ctx {
     rt_scene_info info{};
     // scene buffers
     DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights;
+    DevBuf tri_slot_leaf, sphere_slot_leaf;  // tight tree only (rt_bvh.h)
+    bool build_tight = true;  // RT_OPTION_TIGHT_TREE (takes effect at the next upload and at once for renders)
     int traversal = RT_TRAVERSAL_AUTO;  // RT_OPTION_TRAVERSAL
     int bvh_min_nodes = 0;              // auto: scenes with at least this many flat nodes take the BVH kernel
                                         // (measured faster than the wave walk on every scene)
@@ -143,6 +145,7 @@ int chain_end(rt_ctx* ctx, hipStream_t st) {
 int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st) {
     WfArgs a;
     a.scene = r.scene;
+    if (!ctx->build_tight) a.scene.tight_root = 0u;
     std::memcpy(a.cam, r.cam, sizeof a.cam);
     a.max_bounces = r.max_bounces;
     a.width = r.width, a.height = r.height, a.local_rows = r.local_rows;
@@ -232,6 +235,7 @@ int rt_create(int device_id, rt_ctx** out) {
         const int t = atoi(v);
         if (t >= 1 && t <= 64) ctx->wf_waves_per_cu = t;
     }
+    if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development override
     if (const char* v = getenv("RT_TRAVERSAL")) {  // development override of RT_OPTION_TRAVERSAL
         const int t = atoi(v);
         if (t >= RT_TRAVERSAL_AUTO && t <= RT_TRAVERSAL_WAVEFRONT) ctx->traversal = t;
@@ -259,7 +263,8 @@ void rt_destroy(rt_ctx* ctx) {
     for (DevBuf* b : wf) release(*b);
     DevBuf* all[] = {&ctx->geom,       &ctx->plane_geom, &ctx->tri_slot_id, &ctx->sphere_slot_id, &ctx->spheres_aos,
                      &ctx->planes_aos, &ctx->tris_aos,   &ctx->lights,      &ctx->ticket,         &ctx->fb_rgb,
-                     &ctx->fb_rgba8,   &ctx->fb_pid,     &ctx->fb_fid,      &ctx->fb_stats};
+                     &ctx->fb_rgba8,   &ctx->fb_pid,     &ctx->fb_fid,      &ctx->fb_stats,
+                     &ctx->tri_slot_leaf, &ctx->sphere_slot_leaf};
     for (DevBuf* b : all) release(*b);
     for (DevBuf& b : ctx->ev) release(b);
     delete ctx;
@@ -275,6 +280,13 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
             if (value < RT_TRAVERSAL_AUTO || value > RT_TRAVERSAL_WAVEFRONT)
                 return fail(ctx, RT_ERR_INVALID_ARGUMENT, "traversal must be one of RT_TRAVERSAL_*");
             ctx->traversal = value;
+            return RT_OK;
+        case RT_OPTION_WAVEFRONT_MIN_NODES:
+            if (value < 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "node threshold must be >= 0");
+            ctx->wf_min_nodes = value;
+            return RT_OK;
+        case RT_OPTION_TIGHT_TREE:
+            ctx->build_tight = value != 0;
             return RT_OK;
         case RT_OPTION_SUPERTILE:
             if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "supertile must be 1..64");
@@ -314,12 +326,90 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     // re-treed leaves for the per-lane kernels (only for nested trees, rt_bvh.h)
     rtb::Bvh bvh;
     if (flat.nested) rtb::build(flat, &bvh);
+
+    float extent[3] = {0.0f, 0.0f, 0.0f};
+    if (!flat.nodes.empty()) {
+        const rtf::FlatNode& root = flat.nodes[0];
+        const float lo[3] = {root.minx, root.miny, root.minz}, hi[3] = {root.maxx, root.maxy, root.maxz};
+        for (int k = 0; k < 3; k++) extent[k] = std::fmax(std::fabs(lo[k]), std::fabs(hi[k]));
+    }
+
+    // distance cull precondition: boxes nested, every primitive inside its leaf box (within a slack
+    // far below the cull's pad), triangle normals perpendicular to their triangles; otherwise the
+    // kernels never cull
+    bool contained = flat.nested;
+    if (contained) {
+        const float slack = std::fmax(extent[0], std::fmax(extent[1], extent[2])) * (1.0f / 4096.0f);
+        const unsigned char* T = (const unsigned char*)triangles;
+        const unsigned char* Sp = (const unsigned char*)spheres;
+        for (const rtf::FlatNode& fn : flat.nodes) {
+            const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = fn.meta & 0xFFFFFF;
+            if (kind == rtf::KIND_BRANCH) continue;
+            const float lo[3] = {fn.minx - slack, fn.miny - slack, fn.minz - slack};
+            const float hi[3] = {fn.maxx + slack, fn.maxy + slack, fn.maxz + slack};
+            for (int k = 0; k < count && contained; k++) {
+                if (kind == rtf::KIND_TRI) {
+                    const float* rec = (const float*)(T + (size_t)flat.tri_slot_id[first + k] * 96);
+                    for (int v = 0; v < 3; v++)
+                        for (int c = 0; c < 3; c++) {
+                            const float x = rec[4 * v + c];
+                            if (!(x >= lo[c] && x <= hi[c])) contained = false;
+                        }
+                    // the stored normal must be the triangle's: IntersectTriangle intersects the plane through
+                    // A with THAT normal, and the cull's proof needs the hit point on the triangle.  Measured
+                    // as the distance of B and C from that plane, allowed up to 1/8 of the cull's pad (the
+                    // reference's own sliver triangles reach 3e-3 rad, 0.003 units).  A NaN normal (zero-area
+                    // triangle, 32 of them in the teapot) never produces a hit and is fine.
+                    const float* n = rec + 12;
+                    const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+                    for (int v = 1; v < 3 && nn == nn; v++) {
+                        const double off = std::fabs(((double)rec[4 * v] - rec[0]) * n[0] +
+                                                     ((double)rec[4 * v + 1] - rec[1]) * n[1] +
+                                                     ((double)rec[4 * v + 2] - rec[2]) * n[2]);
+                        if (!(nn > 0) || !(off <= 4.0 * slack * nn)) contained = false;
+                    }
+                } else {
+                    const float* rec = (const float*)(Sp + (size_t)flat.sphere_slot_id[first + k] * 48);
+                    for (int c = 0; c < 3; c++)
+                        if (!(rec[c] - rec[3] >= lo[c] && rec[c] + rec[3] <= hi[c]) || !(rec[3] >= 0)) contained = false;
+                }
+            }
+            if (!contained) break;
+        }
+    }
+
+    // tight per-primitive tree for the staged pipeline's rays (rt_bvh.h build_tight): large scenes
+    // whose primitives were just verified to sit inside their leaves with matching normals
+    rtb::Bvh tight;
+    std::vector<int32_t> tri_slot_leaf, sphere_slot_leaf;
+    const float max_extent = std::fmax(extent[0], std::fmax(extent[1], extent[2]));
+    const float tight_e = 4.0f * max_extent;  // origins up to 3 scene radii from the world origin
+    if (ctx->build_tight && contained && !bvh.nodes.empty() && (int)flat.nodes.size() >= ctx->wf_min_nodes &&
+        max_extent <= 1e6f) {
+        rtb::TightInput in;
+        in.tris = (const unsigned char*)triangles, in.spheres = (const unsigned char*)spheres;
+        in.pad_tri = tight_e * (1.0f / 16384.0f), in.pad_sphere = tight_e * (1.0f / 256.0f);
+        rtb::build_tight(flat, in, &tight, &tri_slot_leaf, &sphere_slot_leaf);
+        if (tight.levels > rtb::MAX_LEVELS) tight.nodes.clear();
+        // its nodes follow the leaf tree's in one array: inner refs become indices of that array
+        const uint32_t base = (uint32_t)bvh.nodes.size();
+        for (rtb::Node& nd : tight.nodes) {
+            if (!(nd.ref0 & rtb::LEAF)) nd.ref0 += base;
+            if (!(nd.ref1 & rtb::LEAF)) nd.ref1 += base;
+        }
+    }
     // one contiguous geometry image: nodes | triangle slots | sphere slots | BVH nodes (rt_device.h)
     const size_t tri_off = flat.nodes.size() * 2, sph_off = tri_off + (size_t)n_ts * 3;
     const size_t bvh_off = sph_off + (size_t)n_ss;
     const size_t geom_f4 = bvh_off + bvh.nodes.size() * 4;
-    if (geom_f4 >= (size_t)INT32_MAX / 2) return fail(ctx, RT_ERR_TOO_LARGE, "geometry image too large");
-    if ((rc = ensure(ctx, ctx->geom, geom_f4 * 16))) return rc;
+    const size_t all_f4 = geom_f4 + tight.nodes.size() * 4;
+    if (all_f4 >= (size_t)INT32_MAX / 2) return fail(ctx, RT_ERR_TOO_LARGE, "geometry image too large");
+    if ((rc = ensure(ctx, ctx->geom, all_f4 * 16))) return rc;
+    if ((rc = upload(ctx, ctx->tri_slot_leaf, tri_slot_leaf.data(), tri_slot_leaf.size() * 4))) return rc;
+    if ((rc = upload(ctx, ctx->sphere_slot_leaf, sphere_slot_leaf.data(), sphere_slot_leaf.size() * 4))) return rc;
+    if (!tight.nodes.empty())
+        HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + geom_f4, tight.nodes.data(), tight.nodes.size() * sizeof(rtb::Node),
+                               hipMemcpyHostToDevice));
     if (!flat.nodes.empty())
         HIP_TRY(ctx, hipMemcpy(ctx->geom.p, flat.nodes.data(), flat.nodes.size() * 32, hipMemcpyHostToDevice));
     if (!bvh.nodes.empty())
@@ -361,61 +451,16 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     s.n_spheres = n_spheres;
     s.n_tris = n_triangles;
     s.lights_len = lights_len;
-    for (int k = 0; k < 3; k++) s.extent[k] = 0.0f;
-    if (!flat.nodes.empty()) {
-        const rtf::FlatNode& root = flat.nodes[0];
-        const float lo[3] = {root.minx, root.miny, root.minz}, hi[3] = {root.maxx, root.maxy, root.maxz};
-        for (int k = 0; k < 3; k++) s.extent[k] = std::fmax(std::fabs(lo[k]), std::fabs(hi[k]));
-    }
-
-    // distance cull precondition: boxes nested, every primitive inside its leaf box (within a slack
-    // far below the cull's pad), triangle normals perpendicular to their triangles; otherwise the
-    // kernels never cull
-    bool contained = flat.nested;
-    if (contained) {
-        const float slack = std::fmax(s.extent[0], std::fmax(s.extent[1], s.extent[2])) * (1.0f / 4096.0f);
-        const unsigned char* T = (const unsigned char*)triangles;
-        const unsigned char* Sp = (const unsigned char*)spheres;
-        for (const rtf::FlatNode& fn : flat.nodes) {
-            const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = fn.meta & 0xFFFFFF;
-            if (kind == rtf::KIND_BRANCH) continue;
-            const float lo[3] = {fn.minx - slack, fn.miny - slack, fn.minz - slack};
-            const float hi[3] = {fn.maxx + slack, fn.maxy + slack, fn.maxz + slack};
-            for (int k = 0; k < count && contained; k++) {
-                if (kind == rtf::KIND_TRI) {
-                    const float* rec = (const float*)(T + (size_t)flat.tri_slot_id[first + k] * 96);
-                    for (int v = 0; v < 3; v++)
-                        for (int c = 0; c < 3; c++) {
-                            const float x = rec[4 * v + c];
-                            if (!(x >= lo[c] && x <= hi[c])) contained = false;
-                        }
-                    // the stored normal must be the triangle's: IntersectTriangle intersects the plane through
-                    // A with THAT normal, and the cull's proof needs the hit point on the triangle.  Measured
-                    // as the distance of B and C from that plane, allowed up to 1/8 of the cull's pad (the
-                    // reference's own sliver triangles reach 3e-3 rad, 0.003 units).  A NaN normal (zero-area
-                    // triangle, 32 of them in the teapot) never produces a hit and is fine.
-                    const float* n = rec + 12;
-                    const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
-                    for (int v = 1; v < 3 && nn == nn; v++) {
-                        const double off = std::fabs(((double)rec[4 * v] - rec[0]) * n[0] +
-                                                     ((double)rec[4 * v + 1] - rec[1]) * n[1] +
-                                                     ((double)rec[4 * v + 2] - rec[2]) * n[2]);
-                        if (!(nn > 0) || !(off <= 4.0 * slack * nn)) contained = false;
-                    }
-                } else {
-                    const float* rec = (const float*)(Sp + (size_t)flat.sphere_slot_id[first + k] * 48);
-                    for (int c = 0; c < 3; c++)
-                        if (!(rec[c] - rec[3] >= lo[c] && rec[c] + rec[3] <= hi[c]) || !(rec[3] >= 0)) contained = false;
-                }
-            }
-            if (!contained) break;
-        }
-    }
+    for (int k = 0; k < 3; k++) s.extent[k] = extent[k];
     s.cull_scale = contained ? 0.0078125f : INFINITY;
 
     s.bvh = bvh.nodes.empty() ? nullptr : (const float4*)ctx->geom.p + bvh_off;
-    s.bvh_levels = bvh.levels;
+    s.bvh_levels = std::max(bvh.levels, tight.nodes.empty() ? 0 : tight.levels);
     s.bvh_off = (int32_t)bvh_off;
+    s.tight_root = tight.nodes.empty() ? 0u : (uint32_t)bvh.nodes.size();
+    s.tight_e = tight_e;
+    s.tri_slot_leaf = (const int32_t*)ctx->tri_slot_leaf.p;
+    s.sphere_slot_leaf = (const int32_t*)ctx->sphere_slot_leaf.p;
 
     rt_scene_info& inf = ctx->info;
     std::memset(&inf, 0, sizeof inf);
@@ -432,6 +477,9 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     inf.bvh_levels = bvh.levels;
     inf.flags = (flat.nested ? RT_SCENE_NESTED : 0) | (contained ? RT_SCENE_CULL : 0);
     inf.device_bytes += (int64_t)(bvh.nodes.size() * sizeof(rtb::Node));
+    inf.tight_nodes = (int64_t)tight.nodes.size();
+    inf.tight_levels = tight.nodes.empty() ? 0 : tight.levels;
+    inf.device_bytes += (int64_t)(tight.nodes.size() * sizeof(rtb::Node) + (tri_slot_leaf.size() + sphere_slot_leaf.size()) * 4);
     ctx->lds_capable = !bvh.nodes.empty() && ctx->lds_bytes <= (size_t)ctx->lds_limit;
     ctx->has_scene = true;
     return RT_OK;

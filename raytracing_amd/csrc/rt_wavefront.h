@@ -112,7 +112,7 @@ __device__ __forceinline__ void wf_run(const GeomBvh& g, uint32_t* head, uint32_
         const int n_idle = __popcll(idle_m);
         if (!exhausted && n_idle >= WF_REFILL) {
             const uint32_t k = wf_draw(head, total, cur == NONE, &exhausted);
-            if (k != NONE && job.setup(k)) cur = 0u, sp = 0, lk = 0;  // node 0 = root holder
+            if (k != NONE && job.setup(k)) cur = job.tight ? job.a.scene.tight_root : 0u, sp = 0, lk = 0;  // a root holder
             continue;
         }
         if (n_idle == 64) {
@@ -127,8 +127,15 @@ __device__ __forceinline__ void wf_run(const GeomBvh& g, uint32_t* head, uint32_
                 const float th = job.t_hi();
                 float e0, e1;
                 const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
-                const bool h0 = IntersectBoundingBoxCull(job.br, q0, q1, job.t_lo, th, &e0) & (r0 != LEAF);
-                const bool h1 = IntersectBoundingBoxCull(job.br, q2, q3, job.t_lo, th, &e1) & (r1 != LEAF);
+                bool h0, h1;
+                if (job.tight) {  // conservative filter (rt_bvh.h build_tight)
+                    h0 = SlabHit(job.br, q0, q1, job.t_lo, th, &e0);
+                    h1 = SlabHit(job.br, q2, q3, job.t_lo, th, &e1);
+                } else {  // the reference's test on the reference's leaf boxes
+                    h0 = IntersectBoundingBoxCull(job.br, q0, q1, job.t_lo, th, &e0);
+                    h1 = IntersectBoundingBoxCull(job.br, q2, q3, job.t_lo, th, &e1);
+                }
+                h0 &= r0 != LEAF, h1 &= r1 != LEAF;
                 if (h0 & h1) {
                     const bool swap = e1 < e0;
                     stk[64 * sp++] = swap ? r0 : r1;
@@ -176,18 +183,24 @@ struct WfClosestJob {
     V3 o, d;
     BoxRay br;
     Closest h;
+    bool tight;  // this ray walks the tight tree: hits count only if their reference leaf box passes
     __device__ __forceinline__ float t_hi() const { return h.t; }
     __device__ __forceinline__ bool done() const { return false; }
+    __device__ __forceinline__ bool leaf_passes(const int32_t* slot_leaf, int slot) const {
+        if (!tight) return true;
+        const int leaf = slot_leaf[slot];
+        return IntersectBoundingBox(br, g.node_lo(leaf), g.node_hi(leaf));
+    }
     __device__ __forceinline__ void sphere(int slot) {
         const float4 s = g.sphere(slot);
         const float t = IntersectSphereT(o, d, v3(s.x, s.y, s.z), s.w);
-        if (closer(t, 0, slot, t_lo, h)) h.t = t, h.kind = 0, h.index = slot;
+        if (closer(t, 0, slot, t_lo, h) && leaf_passes(a.scene.sphere_slot_leaf, slot)) h.t = t, h.kind = 0, h.index = slot;
     }
     __device__ __forceinline__ void tri(int slot) {
         const TriG tg = load_tri(g, slot);
         const float t = IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N,
                                                   [&](float tt) { return closer(tt, 2, slot, t_lo, h); });
-        if (closer(t, 2, slot, t_lo, h)) h.t = t, h.kind = 2, h.index = slot;
+        if (closer(t, 2, slot, t_lo, h) && leaf_passes(a.scene.tri_slot_leaf, slot)) h.t = t, h.kind = 2, h.index = slot;
     }
     __device__ __forceinline__ void finish() const {
         if (a.iter == 0) {
@@ -218,7 +231,11 @@ struct WfClosestJob {
             const float t = IntersectPlane(o, d, v3(pp.x, pp.y, pp.z), v3(nn.x, nn.y, nn.z));
             if (closer(t, 1, q, t_lo, h)) h.t = t, h.kind = 1, h.index = q;
         }
-        if (ray_is_regular(br) && S.n_nodes > 0) return true;
+        tight = false;
+        if (ray_is_regular(br) && S.n_nodes > 0) {
+            tight = S.tight_root != 0u && make_tight_ray(br, v3(S.extent[0], S.extent[1], S.extent[2]), S.tight_e);
+            return true;
+        }
         // zero direction component etc.: the exact tree, exhaustively (rare)
         walk<false>(
             g, S.n_nodes, br, 3, false, nullptr,
@@ -274,16 +291,24 @@ struct WfAnyJob {
     float dist;
     BoxRay br;
     bool blocked;
+    bool tight;  // as in WfClosestJob
     __device__ __forceinline__ float t_hi() const { return dist; }
     __device__ __forceinline__ bool done() const { return blocked; }
     __device__ __forceinline__ bool in_range(float t) const { return t > RT_EPSILON && t < dist; }
+    __device__ __forceinline__ bool leaf_passes(const int32_t* slot_leaf, int slot) const {
+        if (!tight) return true;
+        const int leaf = slot_leaf[slot];
+        return IntersectBoundingBox(br, g.node_lo(leaf), g.node_hi(leaf));
+    }
     __device__ __forceinline__ void sphere(int slot) {
         const float4 s = g.sphere(slot);
-        if (in_range(IntersectSphereT(o, d, v3(s.x, s.y, s.z), s.w))) blocked = true;
+        if (in_range(IntersectSphereT(o, d, v3(s.x, s.y, s.z), s.w)) && leaf_passes(a.scene.sphere_slot_leaf, slot))
+            blocked = true;
     }
     __device__ __forceinline__ void tri(int slot) {
         const TriG tg = load_tri(g, slot);
-        if (in_range(IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N, [&](float t) { return in_range(t); })))
+        if (in_range(IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N, [&](float t) { return in_range(t); })) &&
+            leaf_passes(a.scene.tri_slot_leaf, slot))
             blocked = true;
     }
     __device__ __forceinline__ void finish() const { a.blocked[item] = blocked ? 1 : 0; }
@@ -319,7 +344,11 @@ struct WfAnyJob {
             const float4 pp = S.plane_geom[2 * q], nn = S.plane_geom[2 * q + 1];
             if (in_range(IntersectPlane(o, d, v3(pp.x, pp.y, pp.z), v3(nn.x, nn.y, nn.z)))) blocked = true;
         }
-        if (!blocked && ray_is_regular(br) && S.n_nodes > 0) return true;
+        tight = false;
+        if (!blocked && ray_is_regular(br) && S.n_nodes > 0) {
+            tight = S.tight_root != 0u && make_tight_ray(br, v3(S.extent[0], S.extent[1], S.extent[2]), S.tight_e);
+            return true;
+        }
         if (!blocked)
             walk<false>(
                 g, S.n_nodes, br, 3, false, nullptr,

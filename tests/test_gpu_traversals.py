@@ -11,13 +11,21 @@ from raytracing_amd.host import Scene
 
 pytestmark = pytest.mark.gpu
 
-MODES = [(1, "wave"), (2, "bvh"), (3, "wavefront")]
+# 3 = the staged pipeline on the re-treed leaf boxes only, 4 = with the tight per-primitive tree in front
+# (built for every scene size here; by default only large scenes get it)
+MODES = [(1, "wave"), (2, "bvh"), (3, "wavefront"), (4, "wavefront+tight")]
+
+
+def _set_mode(rt, mode):
+    rt.set_option(rt.OPTION_TIGHT_TREE, 0 if mode == 3 else 1)
+    rt.set_option(rt.OPTION_WAVEFRONT_MIN_NODES, 0 if mode == 4 else 30000)
+    rt.set_option(rt.OPTION_TRAVERSAL, min(mode, 3))
 
 
 @pytest.fixture()
 def rt_mode(rt):
     yield rt
-    rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)
+    _set_mode(rt, 0)
 
 
 def _render(rt, sc, cam, depth, **kw):
@@ -33,7 +41,7 @@ def test_every_traversal_matches_the_oracle(mode, label, name, params, depth, rt
     from raytracing_amd import host
     rt = rt_mode
     sc = scene_of(name, params)
-    rt.set_option(rt.OPTION_TRAVERSAL, mode)
+    _set_mode(rt, mode)
     g = np.random.default_rng(7)
     cams = [sc.camera_for(160, 90)]
     pos = g.uniform([-8, 1, -10], [8, 12, 10])
@@ -45,6 +53,7 @@ def test_every_traversal_matches_the_oracle(mode, label, name, params, depth, rt
         assert_frame_matches(out, ref, f"{name} {label}")
     info = rt.scene_info()
     assert info["flags"] == 3 and info["bvh_nodes"] > 0 and 0 < info["bvh_levels"] <= 32
+    assert (info["tight_nodes"] > 0) == (mode == 4) and info["tight_levels"] <= 32
 
 
 @pytest.mark.parametrize("mode,label", MODES, ids=[m[1] for m in MODES])
@@ -83,7 +92,7 @@ def test_axis_aligned_rays(mode, label, rt_mode):
     sc = Scene(sph, pl, tri, accel, lights, cam)
     ref = oracle_render(sc, cam, 4)
     assert (ref["primary_id"] >= 0).all()
-    rt.set_option(rt.OPTION_TRAVERSAL, mode)
+    _set_mode(rt, mode)
     out = _render(rt, sc, cam, 4)
     assert_frame_matches(out, ref, "axis-aligned " + label)
     slow = _render(rt, sc, cam, 4, stats=True)
@@ -110,7 +119,7 @@ def test_equal_t_across_leaves_takes_the_first_in_reference_order(mode, label, r
     ref = oracle_render(sc, cam, 2)
     hit = ref["primary_id"][ref["primary_id"] >= 0]
     assert len(hit) > 200 and len(np.unique(hit)) == 1
-    rt.set_option(rt.OPTION_TRAVERSAL, mode)
+    _set_mode(rt, mode)
     assert_frame_matches(_render(rt, sc, cam, 2), ref, "coincident " + label)
 
 
@@ -128,10 +137,10 @@ def test_hand_made_tree_without_nesting_falls_back(rt_mode, scene_of):
     good_ref = oracle_render(sc, cam, 1)
     assert not np.array_equal(ref["primary_id"], good_ref["primary_id"])  # the shrunken root does hide hits
     for mode, label in MODES + [(0, "auto")]:
-        rt.set_option(rt.OPTION_TRAVERSAL, mode)
+        _set_mode(rt, mode)
         out = _render(rt, bad, cam, 1)
         info = rt.scene_info()
-        assert info["flags"] == 0 and info["bvh_nodes"] == 0
+        assert info["flags"] == 0 and info["bvh_nodes"] == 0 and info["tight_nodes"] == 0
         assert_frame_matches(out, ref, "not nested " + label)
 
 
@@ -147,8 +156,9 @@ def test_all_traversals_agree_at_full_size_soup1m(rt_mode, scene_of):
     st = slow["stats"]
     assert st["primary_rays"] == 3840 * 2160
     for mode, label in [(3, "wavefront"), (2, "bvh"), (0, "auto")]:
-        rt.set_option(rt.OPTION_TRAVERSAL, mode)
+        _set_mode(rt, mode)
         fast = _render(rt, sc, cam, 4, want=want)
+        assert (rt.scene_info()["tight_nodes"] > 0) == (mode != 3)
         assert np.array_equal(fast["primary_id"], slow["primary_id"]), label
         assert np.array_equal(fast["final_id"], slow["final_id"]), label
         assert np.array_equal(fast["rgb"].view(np.uint32), slow["rgb"].view(np.uint32)), label
@@ -169,7 +179,7 @@ def test_wavefront_renders_issued_on_two_streams_do_not_mix(rt_mode, scene_of):
     rt.SendPrimitivesToShader(sc)
     w, h = 320, 180
     cams = [sc.camera_for(w, h), host.camera_pack([30, 25, -70], [-0.3, -0.2, 1], [1, 0, 0.3], 1.0, 1.6, 0.9, w, h)]
-    rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_WAVEFRONT)
+    _set_mode(rt, 4)
     main = torch.cuda.current_stream()
     ref = []
     for cam in cams:
@@ -201,7 +211,48 @@ def test_normals_that_are_not_the_triangles_switch_the_cull_off(rt_mode, scene_o
     cam = skew.camera_for(160, 90)
     ref = oracle_render(skew, cam, 1)
     for mode, label in MODES:
-        rt.set_option(rt.OPTION_TRAVERSAL, mode)
+        _set_mode(rt, mode)
         out = _render(rt, skew, cam, 1)
         assert rt.scene_info()["flags"] == 1      # nested, but no cull
+        assert rt.scene_info()["tight_nodes"] == 0
         assert_frame_matches(out, ref, "skewed normals " + label)
+
+
+def test_slightly_skewed_normals_keep_the_cull_and_the_tight_tree(rt_mode, scene_of):
+    """Normals a little off their triangles (the reference's own importer yields up to 3e-3 rad on
+    slivers) stay inside the cull's tolerance.  IntersectTriangle then accepts points of the plane
+    through A with the STORED normal whose projection along it falls into ABC: the tight boxes must be
+    fitted to that region, not to the vertices."""
+    rt = rt_mode
+    sc = scene_of("TeapotScene")
+    tri = sc.trianglesData.copy()
+    g = np.random.default_rng(11)
+    n = tri["Normal"] + g.normal(scale=0.002, size=tri["Normal"].shape).astype(np.float32)
+    tri["Normal"] = n / np.linalg.norm(n, axis=1, keepdims=True)
+    skew = Scene(sc.spheresData, sc.planesData, tri, sc.AccelerationStructureData, sc.lightsData, sc.cameraData)
+    cam = skew.camera_for(320, 180)
+    ref = oracle_render(skew, cam, 1, threads=16)
+    for mode, label in MODES:
+        _set_mode(rt, mode)
+        out = _render(rt, skew, cam, 1)
+        info = rt.scene_info()
+        assert info["flags"] == 3 and (info["tight_nodes"] > 0) == (mode == 4)
+        assert_frame_matches(out, ref, "slightly skewed normals " + label)
+
+
+def test_rays_from_far_outside_the_scene_skip_the_tight_tree(rt_mode, scene_of):
+    """The tight boxes are padded for ray origins within 3 scene radii of the world origin; a camera
+    further out must fall back to the leaf-box tree for its primary rays (and still use the tight tree
+    for the shadow and bounce rays that start inside the scene)."""
+    from raytracing_amd import host
+    rt = rt_mode
+    sc = scene_of("Soup", [8000, 80, 8])
+    _set_mode(rt, 4)
+    for dist in (100.0, 1000.0, 30000.0):
+        cam = host.camera_pack([0, 0.3 * dist + 10, -dist], [0, -0.3, 1], [1, 0, 0], 1.0, 0.8 * 40 / dist, 0.45 * 40 / dist,
+                               160, 90)
+        ref = oracle_render(sc, cam, 4, threads=16)
+        assert (ref["primary_id"] >= 0).mean() > 0.2
+        out = _render(rt, sc, cam, 4)
+        assert rt.scene_info()["tight_nodes"] > 0
+        assert_frame_matches(out, ref, f"camera at {dist}")

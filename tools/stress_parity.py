@@ -8,6 +8,7 @@ from raytracing_amd import RayTracer, host
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rt = RayTracer(0)
+rt.set_option(rt.OPTION_WAVEFRONT_MIN_NODES, 0)   # every scene gets the tight tree: mode 3 walks it
 g = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 scenes = [("TestScene1", None, 10, 12.0), ("TeapotTable", None, 8, 12.0), ("Soup", [20000, 200, 8], 4, 60.0),
           ("Soup", [300000, 3000, 8], 3, 60.0)]
