@@ -46,6 +46,13 @@ WORKLOADS = {
 }
 
 
+def parse_workload(spec):
+    """Ad-hoc workload for the development tools: 'Scene:p1,p2,..:WxH:depth', e.g. 'Soup:20000,200,8:1920x1080:4'."""
+    scene, params, size, depth = spec.split(":")
+    w, h = size.split("x")
+    return scene, ([int(v) for v in params.split(",")] if params else None), int(w), int(h), int(depth)
+
+
 def algorithmic_bytes(stats, width, height):
     """bytes the reference algorithm needs per frame (every candidate tested)."""
     return (32 * stats["node_tests"] + 4 * stats["refs_read"] + 16 * stats["sphere_tests"] +

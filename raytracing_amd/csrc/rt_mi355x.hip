@@ -49,8 +49,8 @@ struct rt_ctx {
     bool allow_lds = false;     // RT_OPTION_USE_LDS: opt-in, measured slower than the L2-resident walk
     // path state of the wavefront pipeline (rt_wavefront.h; grow only)
     DevBuf wf_org, wf_dir, wf_mult, wf_final, wf_list0, wf_list1, wf_blocked, wf_counters;
-    int wf_min_nodes = 30000;  // auto: scenes with at least this many flat nodes take the wavefront pipeline
-                               // (Soup at 1080p: 28.8 k nodes 26.8 vs 28.2 ms for the megakernel, 11.5 k nodes 19.7 vs 15.5)
+    int wf_min_nodes = 8000;   // auto: scenes with at least this many flat nodes take the wavefront pipeline
+                               // (Soup at 1080p with the tight tree: 5.7 k nodes 9.7 vs 10.1 ms for the megakernel, 2.9 k nodes 8.9 vs 6.4)
     int wf_max_bounces = 64;   // beyond this the per-bounce launches stop paying: megakernel instead
     int wf_waves_per_cu = 24;  // persistent waves of the two trace stages
     // The wavefront path state and the LDS kernel's ticket counter are per context: renders that use
@@ -235,7 +235,8 @@ int rt_create(int device_id, rt_ctx** out) {
         const int t = atoi(v);
         if (t >= 1 && t <= 64) ctx->wf_waves_per_cu = t;
     }
-    if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development override
+    if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development overrides
+    if (const char* v = getenv("RT_WF_MIN_NODES")) ctx->wf_min_nodes = std::max(0, atoi(v));
     if (const char* v = getenv("RT_TRAVERSAL")) {  // development override of RT_OPTION_TRAVERSAL
         const int t = atoi(v);
         if (t >= RT_TRAVERSAL_AUTO && t <= RT_TRAVERSAL_WAVEFRONT) ctx->traversal = t;

@@ -66,10 +66,14 @@ __device__ __forceinline__ const uint32_t* wf_list_in(const WfArgs& a) { return 
 __device__ __forceinline__ uint32_t* wf_list_out(const WfArgs& a) { return (a.iter & 1) ? a.list[0] : a.list[1]; }
 __device__ __forceinline__ uint32_t wf_active_count(const WfArgs& a) { return a.iter == 0 ? a.n0 : a.counters[4 * a.iter]; }
 
-#ifndef RT_WF_REFILL
-#define RT_WF_REFILL 24
+#ifndef RT_WF_VOTE
+#define RT_WF_VOTE 3  // a node step needs this many times as many lanes as stand at a leaf (wf_run)
 #endif
-constexpr int WF_REFILL = RT_WF_REFILL;  // idle lanes that trigger a refill (measured: 8 -> 182 ms, 16 -> 150, 24 -> 147, 48 -> 180 on Soup1M 4K)
+#ifndef RT_WF_REFILL
+#define RT_WF_REFILL 40
+#endif
+constexpr int WF_REFILL = RT_WF_REFILL;  // idle lanes that trigger a refill.  Rays drawn together are neighbours (same light), so a larger
+// draw walks more coherently: with the tight tree 16 -> 95 ms, 24 -> 83, 32 -> 81, 40 -> 78, 48 -> 83 on Soup1M 4K
 
 // Draw work items for the idle lanes of the wave: one atomic per call.  Returns this lane's item or
 // 0xFFFFFFFF; *exhausted becomes true (wave-uniform) once the list has been handed out completely.
@@ -93,10 +97,12 @@ __device__ __forceinline__ uint32_t wf_draw(uint32_t* head, uint32_t total, bool
 // Every lane owns one ray (cur = its current node or leaf, lk = next primitive of the leaf, stack in
 // LDS).  Rays of one wave are at unrelated points of their walks, so instead of letting the wave run
 // "all node steps, then all leaves" (lanes that reached a leaf wait for the longest node chain:
-// measured 25 % lane utilisation) each trip of the loop takes a vote: if at least as many lanes
-// stand at an inner node as at a leaf the wave executes ONE node step, otherwise ONE primitive
-// test.  The executed step is therefore always wanted by >= half of the busy lanes, the others wait
-// one trip.  A lane whose ray ends writes its result and turns idle; once WF_REFILL lanes are idle
+// measured 25 % lane utilisation) each trip of the loop takes a vote: if at least RT_WF_VOTE times as
+// many lanes stand at an inner node as at a leaf the wave executes ONE node step, otherwise ONE
+// primitive test; the others wait one trip.  (On the tight tree a ray takes ~25 node steps per
+// primitive test, so lanes reach leaves a few at a time: waiting for half the wave to stand at a leaf
+// left a quarter of it parked; 3:1 measured best, 83 -> 80 ms on Soup1M 4K.)
+// A lane whose ray ends writes its result and turns idle; once WF_REFILL lanes are idle
 // they draw new rays (wf_draw).  Job supplies the ray: setup(k) -> bool (needs a traversal),
 // t_lo, t_hi(), sphere(slot), tri(slot), done(), finish().
 // ------------------------------------------------------------------------------------------
@@ -121,7 +127,7 @@ __device__ __forceinline__ void wf_run(const GeomBvh& g, uint32_t* head, uint32_
         }
         const bool at_leaf = cur != NONE && (cur & LEAF);
         const int n_leaf = __popcll(__ballot(at_leaf));
-        if (64 - n_idle - n_leaf >= n_leaf) {
+        if (64 - n_idle - n_leaf >= RT_WF_VOTE * n_leaf) {
             if (!(cur & LEAF)) {  // node step (NONE has the leaf bit)
                 const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2), q3 = g.bvh_node(cur, 3);
                 const float th = job.t_hi();

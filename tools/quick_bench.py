@@ -7,7 +7,7 @@ from raytracing_amd import RayTracer, host
 names = sys.argv[1:] or ["teapot_1080p_d1", "teapot_4k_d1", "testscene1_720p_d10", "teapottable_1080p_d8", "soup100k_1080p_d4"]
 rt = RayTracer(0)
 for name in names:
-    sn, pr, w, h, d = B.WORKLOADS[name]
+    sn, pr, w, h, d = B.WORKLOADS[name] if name in B.WORKLOADS else B.parse_workload(name)
     sc = host.make_scene(sn, params=pr)
     rt.SendPrimitivesToShader(sc)
     cam = sc.camera_for(w, h)
