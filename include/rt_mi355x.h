@@ -165,6 +165,10 @@ typedef struct rt_scene_info {
     int64_t traversal;      /* RT_TRAVERSAL_* a default render (max_bounces 10) uses   */
     int64_t tight_nodes;    /* 64-byte nodes of the per-primitive tree (0 = not built) */
     int64_t tight_levels;   /* its depth                                               */
+    int64_t unbounded_triangles; /* triangle slots with (nearly) collinear or coincident vertices as seen
+                               along their stored normal: the reference accepts those on a whole line or
+                               plane, so the distance cull never skips the subtrees that hold them        */
+    int64_t reserved[3];
 } rt_scene_info;
 enum {
     RT_SCENE_NESTED = 1,    /* every box lies inside its parent's (true for every RTree.cs tree) */

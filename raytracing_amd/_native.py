@@ -34,7 +34,8 @@ class rt_scene_info(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("n_nodes", "n_tri_slots", "n_sphere_slots", "max_depth", "device_bytes", "lds_scene_bytes",
                  "bvh_nodes", "bvh_levels", "flags", "traversal")] + \
-               [("tight_nodes", C.c_int64), ("tight_levels", C.c_int64)]
+               [("tight_nodes", C.c_int64), ("tight_levels", C.c_int64), ("unbounded_triangles", C.c_int64),
+                ("reserved", C.c_int64 * 3)]
 
 
 # every symbol include/rt_mi355x.h declares: name -> (restype, argtypes)

@@ -18,8 +18,9 @@
 //
 // Node = 64 B = 4 x float4: {lo0.xyz, ref0 | hi0.xyz, ref1 | lo1.xyz, - | hi1.xyz, -}: both child boxes
 // sit in the parent, so one node fetch decides both children.  ref: bit 31 clear = inner node index;
-// bit 31 set = leaf, bits 30..0 as rtf meta (kind, slot count, first slot).  Node 0 holds the root box
-// as child 0 and an empty leaf as child 1, so a traversal always starts with `cur = 0`.
+// bit 31 set = leaf, bits 30..0 as rtf meta (kind, slot count, first slot); NOCULL below.  Node 0 holds the root box
+// as child 0 and an empty leaf (or the tree of the unbounded leaves, NOCULL below) as child 1, so a
+// traversal always starts with `cur = 0`.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -43,6 +44,15 @@ struct Node {
 static_assert(sizeof(Node) == 64, "BVH node is 64 B");
 
 constexpr uint32_t LEAF = 0x80000000u;
+// "never distance-cull this child": a leaf ref of kind 3 (rtf::KIND_TRI_UNBOUNDED) has bits 30 and 29 set;
+// an inner ref carries both bits when such a leaf lies below it, so one mask test serves both.  Inner
+// node index = ref & INDEX_MASK.
+constexpr uint32_t NOCULL = 0x60000000u;
+constexpr uint32_t INDEX_MASK = 0x1FFFFFFFu;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline bool ref_nocull(uint32_t ref) { return (ref & NOCULL) == NOCULL; }
 constexpr int MAX_LEVELS = 32;  // inner nodes on any root->leaf path, holder included (= stack entries)
 
 struct Bvh {
@@ -162,7 +172,7 @@ struct Builder {
         nd.ref0 = rl, nd.ref1 = rr, nd.pad0 = nd.pad1 = 0;
         box->grow(l.lo, l.hi);
         box->grow(r.lo, r.hi);
-        return me;
+        return me | ((ref_nocull(rl) || ref_nocull(rr)) ? NOCULL : 0u);
     }
     static int bin_of(const Item& it, int ax, float lo, double scale) {
         const double c = 0.5f * it.lo[ax] + 0.5f * it.hi[ax];
@@ -203,9 +213,11 @@ inline void build_items(std::vector<Item>& items, size_t split, Bvh* out) {
 }  // namespace detail
 
 // Re-tree the leaves of a flattened reference tree (flat.nested must hold).  Leaves without
-// primitives are dropped (they have no candidates).  An empty tree yields no nodes.
+// primitives are dropped (they have no candidates).  An empty tree yields no nodes.  Leaves that hold
+// an unbounded triangle (kind 3) get a tree of their own under the root holder's second slot, so the
+// never-cull mark stays off every path of the main tree.
 inline void build(const rtf::Flat& flat, Bvh* out) {
-    std::vector<detail::Item> items;
+    std::vector<detail::Item> items, unbounded;
     for (const rtf::FlatNode& fn : flat.nodes) {
         const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31;
         if (kind == rtf::KIND_BRANCH || count == 0) continue;
@@ -214,9 +226,11 @@ inline void build(const rtf::Flat& flat, Bvh* out) {
         it.hi[0] = fn.maxx, it.hi[1] = fn.maxy, it.hi[2] = fn.maxz;
         it.ref = LEAF | (fn.meta & 0x7FFFFFFFu);
         it.weight = (float)count;
-        items.push_back(it);
+        (kind == rtf::KIND_TRI_UNBOUNDED ? unbounded : items).push_back(it);
     }
-    detail::build_items(items, items.size(), out);
+    const size_t split = items.size();
+    items.insert(items.end(), unbounded.begin(), unbounded.end());
+    detail::build_items(items, split, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -247,6 +261,8 @@ inline void build(const rtf::Flat& flat, Bvh* out) {
 //             the closest approach) by <= sqrt(68 eps)/2 |o-c|, and the closest approach misses the
 //             sphere by at most the same amount: X_c is within 2.0e-3 |o-c| <= 3.5e-3 E of the
 //             sphere.  The box is c +- (r + pad_sphere), pad_sphere = 2^-8 E_build = 3.9e-3 E_build.
+//   unbounded triangles (rtf::meta_nocull: the reference accepts them on a whole line or plane) get
+//             a box no ray misses and hang in the spheres' tree.
 //   slab test errors (fma form, 1/d rounded) are < 6 eps E in space: covered by either pad.
 //
 // E_build is fixed at build time, so only rays with E(o) = max_k(|o_k| + extent_k) <= E_build and a
@@ -257,6 +273,7 @@ struct TightInput {
     const unsigned char* tris = nullptr;     // TriangleStruct records, 96 B: A|_ B|_ C|_ N|_ ...
     const unsigned char* spheres = nullptr;  // SphereStruct records, 48 B: center, radius
     float pad_tri = 0, pad_sphere = 0;
+    const std::vector<uint8_t>* tri_unbounded = nullptr;  // per triangle slot: accepted on a line / plane (rtf::meta_nocull)
 };
 
 inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, std::vector<int32_t>* tri_slot_leaf,
@@ -277,14 +294,24 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
     };
     for (size_t ni = 0; ni < flat.nodes.size(); ni++) {
         const rtf::FlatNode& fn = flat.nodes[ni];
-        const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = (int)(fn.meta & 0xFFFFFF);
+        const int count = (fn.meta >> 24) & 31, first = (int)(fn.meta & 0xFFFFFF);
+        int kind = (fn.meta >> 29) & 3;
         if (kind == rtf::KIND_BRANCH) continue;
+        if (kind == rtf::KIND_TRI_UNBOUNDED) kind = rtf::KIND_TRI;  // decided per slot below
         for (int k = 0; k < count; k++) {
             const int slot = first + k;
             detail::Item it;
             it.weight = 1.0f;
             it.ref = LEAF | ((uint32_t)kind << 29) | (1u << 24) | (uint32_t)slot;
             double lo[3], hi[3], pad;
+            if (kind == rtf::KIND_TRI && in.tri_unbounded && (*in.tri_unbounded)[slot]) {
+                // hits anywhere along a line or plane: a box no ray misses; kept out of the triangles' tree
+                (*tri_slot_leaf)[slot] = (int32_t)ni;
+                for (int c = 0; c < 3; c++) it.lo[c] = -3.402823466e+38f, it.hi[c] = 3.402823466e+38f;
+                it.ref = LEAF | ((uint32_t)rtf::KIND_TRI_UNBOUNDED << 29) | (1u << 24) | (uint32_t)slot;
+                sphere_items.push_back(it);
+                continue;
+            }
             if (kind == rtf::KIND_TRI) {
                 (*tri_slot_leaf)[slot] = (int32_t)ni;
                 const float* r = (const float*)(in.tris + (size_t)flat.tri_slot_id[slot] * 96);

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "rt_bvh.h"
 #include "rt_flatten.h"
 #include "rt_math.h"
 #include "../../include/rt_mi355x.h"
@@ -64,8 +65,12 @@ struct GeomGlobal {
     __device__ __forceinline__ float4 tri(int slot, int k) const { return base[tri_off + 3 * slot + k]; }
     __device__ __forceinline__ float4 sphere(int slot) const { return base[sph_off + slot]; }
 };
-// geometry in HBM/L2 + the re-treed leaves, walked per lane with a stack in LDS (bvh_walk)
-struct GeomBvh {
+// geometry in HBM/L2 + the re-treed leaves, walked per lane with a stack in LDS (bvh_walk).
+// UNB: the scene holds unbounded triangles (rtf::meta_nocull), so child refs must be checked for the
+// never-cull mark; scenes without them run the variant that does not spend instructions on it.
+template <bool UNB>
+struct GeomBvhT {
+    static constexpr bool unbounded = UNB;
     const float4* base;
     int tri_off, sph_off;
     const float4* bvh;
@@ -77,7 +82,9 @@ struct GeomBvh {
     __device__ __forceinline__ float4 node_hi(int i) const { return base[2 * i + 1]; }
     __device__ __forceinline__ float4 tri(int slot, int k) const { return base[tri_off + 3 * slot + k]; }
     __device__ __forceinline__ float4 sphere(int slot) const { return base[sph_off + slot]; }
-    __device__ __forceinline__ float4 bvh_node(uint32_t i, int k) const { return bvh[4 * (size_t)i + k]; }
+    __device__ __forceinline__ float4 bvh_node(uint32_t i, int k) const {
+        return bvh[4 * (size_t)(UNB ? (i & rtb::INDEX_MASK) : i) + k];
+    }
 };
 // dynamic LDS of the kernels that use it; named directly (not through a generic pointer) so that
 // every access is a ds_read / ds_write, never a flat access
@@ -86,6 +93,7 @@ extern __shared__ float4 rt_lds[];
 // scenes): rt_lds[0 ..) holds geometry image [tri_off, geom_float4s).  The exact flat tree (only
 // walked by rays with a zero direction component) stays in global memory.
 struct GeomBvhLds {
+    static constexpr bool unbounded = true;
     const float4* base;
     int sph_l, bvh_l;  // float4 index of the sphere slots / BVH nodes inside rt_lds
     int stack_base;
@@ -96,14 +104,14 @@ struct GeomBvhLds {
     __device__ __forceinline__ float4 node_hi(int i) const { return base[2 * i + 1]; }
     __device__ __forceinline__ float4 tri(int slot, int k) const { return rt_lds[3 * slot + k]; }
     __device__ __forceinline__ float4 sphere(int slot) const { return rt_lds[sph_l + slot]; }
-    __device__ __forceinline__ float4 bvh_node(uint32_t i, int k) const { return rt_lds[bvh_l + 4 * (int)i + k]; }
+    __device__ __forceinline__ float4 bvh_node(uint32_t i, int k) const { return rt_lds[bvh_l + 4 * (int)(i & rtb::INDEX_MASK) + k]; }
 };
 template <class G>
 struct is_bvh {
     static constexpr bool value = false;
 };
-template <>
-struct is_bvh<GeomBvh> {
+template <bool UNB>
+struct is_bvh<GeomBvhT<UNB>> {
     static constexpr bool value = true;
 };
 template <>
@@ -211,7 +219,7 @@ __device__ __forceinline__ bool IntersectBoundingBox(const BoxRay& r, float4 lo,
 // worst case is a grazing ray, discriminant ~ 0).  pad = E/128 = 7.8e-3*E covers both.  NaN slab
 // values (zero direction components) make every comparison false: no cull, as in the reference.
 __device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4 lo, float4 hi, float t_lo,
-                                                         float t_hi, float* entry = nullptr) {
+                                                         float t_hi, float* entry = nullptr, bool nocull = false) {
     const float txn = ((r.sx ? hi.x : lo.x) - r.o.x) * r.inv.x;
     const float txf = ((r.sx ? lo.x : hi.x) - r.o.x) * r.inv.x;
     const float tyn = ((r.sy ? hi.y : lo.y) - r.o.y) * r.inv.y;
@@ -226,9 +234,10 @@ __device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4
     const float tzf = ((r.sz ? lo.z : hi.z) - r.o.z) * r.inv.z;
     const bool miss_z = (mn > tzf) | (tzn > mf);
     // ---- not in the reference: padded-interval cull ----
+    // nocull: an unbounded triangle lies below this box (rtf::meta_nocull): its hits are not near it
     const float en = fmaxf(fmaxf(txn - r.padinv.x, tyn - r.padinv.y), tzn - r.padinv.z);
     const float ef = fminf(fminf(txf + r.padinv.x, tyf + r.padinv.y), tzf + r.padinv.z);
-    const bool culled = (en > t_hi) | (ef < t_lo);
+    const bool culled = ((en > t_hi) | (ef < t_lo)) & !nocull;
     if (entry) *entry = en;  // padded entry parameter: orders the two children of a BVH node
     return !(miss_xy | miss_z | culled);
 }

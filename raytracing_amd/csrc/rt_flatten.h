@@ -31,11 +31,24 @@ static_assert(sizeof(FlatNode) == 32, "node record is 32 B");
 // meta layout
 //   bit 31      continuation: same logical reference node as the previous record (a mixed or
 //               oversized leaf is cut into homogeneous pieces of <= 31 slots)
-//   bits 30..29 kind: 0 branch, 1 sphere leaf, 2 triangle leaf
-//   bits 28..24 leaf: slot count (0..31)
+//   bits 30..29 kind: 0 branch, 1 sphere leaf, 2 triangle leaf, 3 triangle leaf that holds an unbounded
+//               triangle (set by the upload, see meta_nocull)
+//   bits 28..24 leaf: slot count (0..31); branch: bit 24 = an unbounded triangle somewhere below
 //   bits 23..0  leaf: first slot; branch: child count (for the refs_read counter)
 constexpr uint32_t META_CONT = 1u << 31;
-constexpr int KIND_BRANCH = 0, KIND_SPHERE = 1, KIND_TRI = 2;
+constexpr int KIND_BRANCH = 0, KIND_SPHERE = 1, KIND_TRI = 2, KIND_TRI_UNBOUNDED = 3;
+constexpr uint32_t META_BRANCH_NOCULL = 1u << 24;
+// A triangle whose vertices are (nearly) collinear or coincident as seen along its stored normal is
+// accepted by the reference on a whole line or plane (its three edge tests degenerate), wherever the
+// ray passes the leaf's box test -- which has no distance bound.  Subtrees that hold such a triangle
+// must never be skipped by the distance cull (rt_device.h IntersectBoundingBoxCull).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline bool meta_nocull(uint32_t meta) {
+    const uint32_t kind = (meta >> 29) & 3u;
+    return kind == (uint32_t)KIND_TRI_UNBOUNDED || (kind == (uint32_t)KIND_BRANCH && (meta & META_BRANCH_NOCULL));
+}
 constexpr int MAX_LEAF_SLOTS = 31;
 constexpr int64_t SLOT_LIMIT = 1 << 24;
 inline uint32_t make_meta(bool cont, int kind, int count, int64_t first) {
@@ -52,6 +65,7 @@ struct Flat {
     // every tree RTree.cs builds: UpdateBoundingBox takes the exact min/max of the children,
     // RTree.cs:332-377).  rt_bvh.h may re-tree the leaves only when this holds.
     bool nested = true;
+    std::vector<int32_t> parent;  // per record: index of the parent branch, -1 for the root, -2 for continuation records
 };
 
 enum { FLATTEN_OK = 0, FLATTEN_MALFORMED = -2, FLATTEN_TOO_LARGE = -6 };
@@ -73,6 +87,7 @@ inline int flatten(const float* acc, int64_t len, int64_t n_spheres, int64_t n_t
     out->max_depth = 0;
     out->logical_nodes = 0;
     out->nested = true;
+    out->parent.clear();
     if (len == 0) return FLATTEN_OK;  // empty scene (RTree.cs:114-115): nothing to traverse
     if (len < 8 || acc == nullptr) {
         *err = "accel array shorter than one node header";
@@ -84,8 +99,9 @@ inline int flatten(const float* acc, int64_t len, int64_t n_spheres, int64_t n_t
         int32_t depth;
     };
     std::vector<Pending> stack;
-    std::vector<int32_t> parent;  // per flat node; -2 for continuation records
-    std::vector<int32_t> size;    // subtree size in flat records
+    std::vector<int32_t>& parent = out->parent;
+    parent.clear();
+    std::vector<int32_t> size;  // subtree size in flat records
     stack.push_back({0, -1, 0});
     const int64_t node_budget = len / 8 + 1;  // every logical node owns >= 8 floats
     std::vector<int64_t> sph, tri;
@@ -186,6 +202,18 @@ inline int flatten(const float* acc, int64_t len, int64_t n_spheres, int64_t n_t
     }
     for (size_t i = 0; i < out->nodes.size(); i++) out->nodes[i].skip = (int32_t)(i + size[i]);
     return FLATTEN_OK;
+}
+
+// Mark the triangle-leaf record `leaf` and all its ancestors as "never distance-cull" (meta_nocull).
+inline void mark_unbounded(Flat* flat, int32_t leaf) {
+    FlatNode& fn = flat->nodes[leaf];
+    fn.meta = (fn.meta & ~(3u << 29)) | ((uint32_t)KIND_TRI_UNBOUNDED << 29);
+    int32_t i = leaf;
+    while (flat->parent[i] == -2) i--;  // continuation records hang under the first piece's parent
+    for (i = flat->parent[i]; i >= 0; i = flat->parent[i]) {
+        if (flat->nodes[i].meta & META_BRANCH_NOCULL) break;  // the rest of the path is marked already
+        flat->nodes[i].meta |= META_BRANCH_NOCULL;
+    }
 }
 
 }  // namespace rtf

@@ -77,7 +77,7 @@ __device__ __forceinline__ void wave_walk(const G& g, int n_nodes, const BoxRay&
         const uint32_t meta = __float_as_uint(hi.w);
         const int skip = __float_as_int(lo.w);
         const bool active = i >= resume;
-        const bool hit = active && IntersectBoundingBoxCull(br, lo, hi, t_lo, t_hi());
+        const bool hit = active && IntersectBoundingBoxCull(br, lo, hi, t_lo, t_hi(), nullptr, rtf::meta_nocull(meta));
         if (active && !hit) resume = skip;
         if (__ballot(hit) == 0ull) {
             i = skip;
@@ -121,7 +121,8 @@ __device__ __forceinline__ void wave_walk(const G& g, int n_nodes, const BoxRay&
 template <class G>
 __device__ __forceinline__ uint32_t bvh_enter(const G& g, const BoxRay& br, float t_lo, float t_hi) {
     const float4 q0 = g.bvh_node(0, 0), q1 = g.bvh_node(0, 1);
-    return IntersectBoundingBoxCull(br, q0, q1, t_lo, t_hi) ? __float_as_uint(q0.w) : 0xFFFFFFFFu;
+    const uint32_t r0 = __float_as_uint(q0.w);
+    return IntersectBoundingBoxCull(br, q0, q1, t_lo, t_hi, nullptr, G::unbounded && rtb::ref_nocull(r0)) ? r0 : 0xFFFFFFFFu;
 }
 
 template <class G, class LeafSphere, class LeafTri, class Done, class THi>
@@ -131,7 +132,8 @@ __device__ __forceinline__ void bvh_walk(const G& g, const BoxRay& br, bool aliv
     uint32_t* const stk = (uint32_t*)rt_lds + g.stack_base;
     int sp = 0;
     uint32_t cur = NONE;
-    if (alive) cur = bvh_enter(g, br, t_lo, t_hi());
+    // (scenes with unbounded triangles keep those in a second tree under node 0: take the whole node)
+    if (alive) cur = G::unbounded ? 0u : bvh_enter(g, br, t_lo, t_hi());
     while (cur != NONE) {
         while (!(cur & LEAF)) {
 #ifdef RT_DIAG_STEPS
@@ -141,9 +143,9 @@ __device__ __forceinline__ void bvh_walk(const G& g, const BoxRay& br, bool aliv
             const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2), q3 = g.bvh_node(cur, 3);
             const float th = t_hi();
             float e0, e1;
-            const bool h0 = IntersectBoundingBoxCull(br, q0, q1, t_lo, th, &e0);
-            const bool h1 = IntersectBoundingBoxCull(br, q2, q3, t_lo, th, &e1);
             const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+            const bool h0 = IntersectBoundingBoxCull(br, q0, q1, t_lo, th, &e0, G::unbounded && rtb::ref_nocull(r0));
+            const bool h1 = IntersectBoundingBoxCull(br, q2, q3, t_lo, th, &e1, G::unbounded && rtb::ref_nocull(r1));
             if (h0 & h1) {
                 const bool swap = e1 < e0;
                 stk[64 * sp++] = swap ? r0 : r1;
@@ -558,6 +560,8 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 #ifndef RT_BVH_WAVES_PER_EU
 #define RT_BVH_WAVES_PER_EU 4
 #endif
+// UNB: see GeomBvhT.
+template <bool UNB>
 __global__ __launch_bounds__(64 * BLOCK_WAVES) __attribute__((amdgpu_waves_per_eu(RT_BVH_WAVES_PER_EU, 8))) void k_render_bvh(
     const RenderArgs a) {
     int tx, ty;
@@ -569,9 +573,9 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) __attribute__((amdgpu_waves_per_e
     const bool live = in_image && x < a.width && r < a.local_rows && y < a.height;
 #ifdef RT_DIAG_STEPS
     int diag[4] = {0, 0, 0, 0};
-    const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.bvh_levels + lane, diag};
+    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.bvh_levels + lane, diag};
 #else
-    const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.bvh_levels + lane};
+    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.bvh_levels + lane};
 #endif
     if (live) {
         const PixelOut p =

@@ -181,8 +181,12 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st) {
         a.iter = i;
         // iteration 0 knows its size; later lists are at most as long as the frame
         const int g0 = (int)std::min<size_t>((size_t)trace_grid, (n0 + 63) / 64);
-        hipLaunchKernelGGL(k_wf_closest, dim3(i == 0 ? g0 : trace_grid), dim3(64), lds, st, a);
-        if (a.n_lights > 0) hipLaunchKernelGGL(k_wf_any, dim3(trace_grid), dim3(64), lds, st, a);
+        // <true>: the scene holds unbounded triangles, refs are checked for the never-cull mark
+        const bool unb = ctx->info.unbounded_triangles > 0;
+        hipLaunchKernelGGL(unb ? k_wf_closest<true> : k_wf_closest<false>, dim3(i == 0 ? g0 : trace_grid), dim3(64), lds,
+                           st, a);
+        if (a.n_lights > 0)
+            hipLaunchKernelGGL(unb ? k_wf_any<true> : k_wf_any<false>, dim3(trace_grid), dim3(64), lds, st, a);
         hipLaunchKernelGGL(k_wf_shade, dim3(shade_grid), dim3(256), 0, st, a);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -324,10 +328,6 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     if ((rc = upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), flat.sphere_slot_id.size() * 4)))
         return rc;
     const int n_ts = (int)flat.tri_slot_id.size(), n_ss = (int)flat.sphere_slot_id.size();
-    // re-treed leaves for the per-lane kernels (only for nested trees, rt_bvh.h)
-    rtb::Bvh bvh;
-    if (flat.nested) rtb::build(flat, &bvh);
-
     float extent[3] = {0.0f, 0.0f, 0.0f};
     if (!flat.nodes.empty()) {
         const rtf::FlatNode& root = flat.nodes[0];
@@ -339,6 +339,8 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     // far below the cull's pad), triangle normals perpendicular to their triangles; otherwise the
     // kernels never cull
     bool contained = flat.nested;
+    std::vector<uint8_t> tri_unbounded(flat.tri_slot_id.size(), 0);
+    std::vector<int32_t> unbounded_leaves;
     if (contained) {
         const float slack = std::fmax(extent[0], std::fmax(extent[1], extent[2])) * (1.0f / 4096.0f);
         const unsigned char* T = (const unsigned char*)triangles;
@@ -360,14 +362,36 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
                     // A with THAT normal, and the cull's proof needs the hit point on the triangle.  Measured
                     // as the distance of B and C from that plane, allowed up to 1/8 of the cull's pad (the
                     // reference's own sliver triangles reach 3e-3 rad, 0.003 units).  A NaN normal (zero-area
-                    // triangle, 32 of them in the teapot) never produces a hit and is fine.
+                    // triangle, 32 of them in the teapot) or a zero normal never produces a hit and is fine.
                     const float* n = rec + 12;
                     const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
-                    for (int v = 1; v < 3 && nn == nn; v++) {
+                    for (int v = 1; v < 3 && nn == nn && nn > 0; v++) {
                         const double off = std::fabs(((double)rec[4 * v] - rec[0]) * n[0] +
                                                      ((double)rec[4 * v + 1] - rec[1]) * n[1] +
                                                      ((double)rec[4 * v + 2] - rec[2]) * n[2]);
-                        if (!(nn > 0) || !(off <= 4.0 * slack * nn)) contained = false;
+                        if (!(off <= 4.0 * slack * nn)) contained = false;
+                    }
+                    // ... and the triangle must have an area as seen along that normal.  The three edge tests
+                    // accept the intersection of three half-planes; for collinear (projected) vertices that
+                    // is a whole line, for coincident vertices the whole plane: the reference then accepts
+                    // hits far outside any box around the vertices (they pass the leaf box test, which has
+                    // no distance bound).  Width/length below 1e-5 is within rounding of that case (the
+                    // reference's table model has 19 such triangles).  These are marked, not refused:
+                    // the distance cull leaves their subtrees alone (rtf::meta_nocull).
+                    if (nn == nn && nn > 0) {
+                        const double e1[3] = {(double)rec[4] - rec[0], (double)rec[5] - rec[1], (double)rec[6] - rec[2]};
+                        const double e2[3] = {(double)rec[8] - rec[0], (double)rec[9] - rec[1], (double)rec[10] - rec[2]};
+                        const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
+                        const double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2],
+                                              e1[0] * e2[1] - e1[1] * e2[0]};
+                        const double area2 = std::fabs(cr[0] * n[0] + cr[1] * n[1] + cr[2] * n[2]) / nn;
+                        const double len2 = std::max({e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2],
+                                                      e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2],
+                                                      e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]});
+                        if (!(area2 > 0) || !(area2 >= 1e-5 * len2)) {
+                            tri_unbounded[first + k] = 1;
+                            unbounded_leaves.push_back((int32_t)(&fn - flat.nodes.data()));
+                        }
                     }
                 } else {
                     const float* rec = (const float*)(Sp + (size_t)flat.sphere_slot_id[first + k] * 48);
@@ -378,6 +402,11 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
             if (!contained) break;
         }
     }
+    if (contained)
+        for (int32_t leaf : unbounded_leaves) rtf::mark_unbounded(&flat, leaf);
+    // re-treed leaves for the per-lane kernels (only for nested trees, rt_bvh.h)
+    rtb::Bvh bvh;
+    if (flat.nested) rtb::build(flat, &bvh);
 
     // tight per-primitive tree for the staged pipeline's rays (rt_bvh.h build_tight): large scenes
     // whose primitives were just verified to sit inside their leaves with matching normals
@@ -390,6 +419,7 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
         rtb::TightInput in;
         in.tris = (const unsigned char*)triangles, in.spheres = (const unsigned char*)spheres;
         in.pad_tri = tight_e * (1.0f / 16384.0f), in.pad_sphere = tight_e * (1.0f / 256.0f);
+        in.tri_unbounded = &tri_unbounded;
         rtb::build_tight(flat, in, &tight, &tri_slot_leaf, &sphere_slot_leaf);
         if (tight.levels > rtb::MAX_LEVELS) tight.nodes.clear();
         // its nodes follow the leaf tree's in one array: inner refs become indices of that array
@@ -477,6 +507,7 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     inf.bvh_nodes = (int64_t)bvh.nodes.size();
     inf.bvh_levels = bvh.levels;
     inf.flags = (flat.nested ? RT_SCENE_NESTED : 0) | (contained ? RT_SCENE_CULL : 0);
+    inf.unbounded_triangles = contained ? (int64_t)std::count(tri_unbounded.begin(), tri_unbounded.end(), 1) : 0;
     inf.device_bytes += (int64_t)(bvh.nodes.size() * sizeof(rtb::Node));
     inf.tight_nodes = (int64_t)tight.nodes.size();
     inf.tight_levels = tight.nodes.empty() ? 0 : tight.levels;
@@ -585,8 +616,8 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
         hipLaunchKernelGGL(k_render_bvh_lds, dim3(grid), dim3(LDS_BLOCK), ctx->lds_bytes, st, a);
         if ((rc = chain_end(ctx, st)) != RT_OK) return rc;
     } else if (use_bvh)
-        hipLaunchKernelGGL(k_render_bvh, dim3(n_blocks), dim3(64 * BLOCK_WAVES),
-                           (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4, st, a);
+        hipLaunchKernelGGL(ctx->info.unbounded_triangles > 0 ? k_render_bvh<true> : k_render_bvh<false>, dim3(n_blocks),
+                           dim3(64 * BLOCK_WAVES), (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4, st, a);
     else
         hipLaunchKernelGGL(k_render<false>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
     HIP_TRY(ctx, hipGetLastError());

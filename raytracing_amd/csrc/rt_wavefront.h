@@ -106,8 +106,8 @@ __device__ __forceinline__ uint32_t wf_draw(uint32_t* head, uint32_t total, bool
 // they draw new rays (wf_draw).  Job supplies the ray: setup(k) -> bool (needs a traversal),
 // t_lo, t_hi(), sphere(slot), tri(slot), done(), finish().
 // ------------------------------------------------------------------------------------------
-template <class Job>
-__device__ __forceinline__ void wf_run(const GeomBvh& g, uint32_t* head, uint32_t total, Job& job) {
+template <class G, class Job>
+__device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t total, Job& job) {
     constexpr uint32_t NONE = 0xFFFFFFFFu, LEAF = 0x80000000u;
     uint32_t* const stk = (uint32_t*)rt_lds + g.stack_base;
     bool exhausted = false;
@@ -138,8 +138,8 @@ __device__ __forceinline__ void wf_run(const GeomBvh& g, uint32_t* head, uint32_
                     h0 = SlabHit(job.br, q0, q1, job.t_lo, th, &e0);
                     h1 = SlabHit(job.br, q2, q3, job.t_lo, th, &e1);
                 } else {  // the reference's test on the reference's leaf boxes
-                    h0 = IntersectBoundingBoxCull(job.br, q0, q1, job.t_lo, th, &e0);
-                    h1 = IntersectBoundingBoxCull(job.br, q2, q3, job.t_lo, th, &e1);
+                    h0 = IntersectBoundingBoxCull(job.br, q0, q1, job.t_lo, th, &e0, G::unbounded && rtb::ref_nocull(r0));
+                    h1 = IntersectBoundingBoxCull(job.br, q2, q3, job.t_lo, th, &e1, G::unbounded && rtb::ref_nocull(r1));
                 }
                 h0 &= r0 != LEAF, h1 &= r1 != LEAF;
                 if (h0 & h1) {
@@ -181,9 +181,10 @@ __device__ __forceinline__ void wf_run(const GeomBvh& g, uint32_t* head, uint32_
 // ------------------------------------------------------------------------------------------
 // closest hit of every active path (FindClosestIntersection, raytracer_fs.glsl:241-297)
 // ------------------------------------------------------------------------------------------
+template <class G>
 struct WfClosestJob {
     const WfArgs& a;
-    const GeomBvh& g;
+    const G& g;
     float t_lo;  // minDistance: 0 for the primary ray, epsilon after a bounce
     int p;
     V3 o, d;
@@ -261,9 +262,10 @@ struct WfClosestJob {
 #ifndef RT_WF_WAVES_PER_EU
 #define RT_WF_WAVES_PER_EU 6  // 80 VGPRs (20 B of spill): Soup1M 4K 148.8 -> 140.3 ms; 8 waves (64 VGPRs) spill 88 B: 375 ms
 #endif
+template <bool UNB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_PER_EU, 8))) void k_wf_closest(const WfArgs a) {
-    const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
-    WfClosestJob job{a, g, a.iter == 0 ? 0.0f : RT_EPSILON};
+    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
+    WfClosestJob<GeomBvhT<UNB>> job{a, g, a.iter == 0 ? 0.0f : RT_EPSILON};
     wf_run(g, a.counters + 4 * a.iter + 1, wf_active_count(a), job);
 }
 
@@ -287,9 +289,10 @@ __device__ __forceinline__ void wf_material_flags(const DevScene& S, int kind, i
 // that fetch together get neighbouring hit points and the SAME light, i.e. near-parallel rays that
 // walk the same nodes (L1/L2 hits), not one point's rays to L different lights.
 // ------------------------------------------------------------------------------------------
+template <class G>
 struct WfAnyJob {
     const WfArgs& a;
-    const GeomBvh& g;
+    const G& g;
     uint32_t n_active;
     float t_lo;  // epsilon
     uint32_t item;
@@ -371,10 +374,11 @@ struct WfAnyJob {
     }
 };
 
+template <bool UNB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_PER_EU, 8))) void k_wf_any(const WfArgs a) {
-    const GeomBvh g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
+    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
     const uint32_t n_active = wf_active_count(a);
-    WfAnyJob job{a, g, n_active, RT_EPSILON};
+    WfAnyJob<GeomBvhT<UNB>> job{a, g, n_active, RT_EPSILON};
     // the last group of 64 paths is padded: setup() skips j >= n_active
     wf_run(g, a.counters + 4 * a.iter + 2, ((n_active + 63u) / 64u) * 64u * (uint32_t)a.n_lights, job);
 }

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_struct_layouts():
     assert C.sizeof(N.rt_stats) == 16 * 8
-    assert C.sizeof(N.rt_scene_info) == 12 * 8
+    assert C.sizeof(N.rt_scene_info) == 16 * 8
     assert (N.SPHERE_DT.itemsize, N.PLANE_DT.itemsize, N.TRIANGLE_DT.itemsize) == (48, 64, 96)
 
 
