@@ -15,6 +15,9 @@ namespace OpenTK
         [DllImport(Lib)] internal static extern int rt_create(int deviceId, out IntPtr ctx);
         [DllImport(Lib)] internal static extern void rt_destroy(IntPtr ctx);
         [DllImport(Lib)] internal static extern IntPtr rt_last_error(IntPtr ctx);   // UTF-8, owned by ctx
+        // tuning knobs, results never depend on them (include/rt_mi355x.h RT_OPTION_*):
+        // 3 = traversal (0 auto), 4 = tight tree on/off, 5 = node count from which a scene counts as large
+        [DllImport(Lib)] internal static extern int rt_set_option(IntPtr ctx, int option, int value);
 
         // replaces SendPrimitivesToShader's GL block, RayTracer.cs:1007-1045
         [DllImport(Lib)] internal static extern int rt_upload_scene(IntPtr ctx,
