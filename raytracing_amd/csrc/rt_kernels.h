@@ -367,6 +367,31 @@ __device__ __forceinline__ V3 mirror_diffuse_term(const DevScene& S, const Surfa
     }
     return combined;
 }
+// Would this light's term of mirror_diffuse_term (mirror) / phong_term add exactly nothing, whatever its
+// shadow ray finds?  Same expressions as those two functions, so the same values: the term is
+// c = 1/d^2 * colour * (diffuse * max0(n.L) [+ specular * pow(max0(D.R), specularity)]), and
+// powf(0, s) == 0 for s > 0.  True only if every component of c is a zero and adding it cannot change
+// the sum (x + 0 == x for every x except x = -0 and c = +0; the sum starts from diffuse * 0.1, so a
+// diffuse without sign bits rules that out).  NaN or inf anywhere makes c != 0: no skip.  The staged
+// pipeline uses this to leave such shadow rays untraced (a light behind the surface whose mirror
+// direction also points away from the viewer: ~40 % of the shadow rays of a triangle soup).
+__device__ __forceinline__ bool light_term_is_zero(const Surface& sf, bool mirror, V3 rayDirection, const LightRay& lr) {
+    V3 c;
+    if (mirror) {
+        c = 1.0f / (lr.dist * lr.dist) * lr.colour * sf.diffuse * max0(dot(sf.normal, lr.L));
+    } else {
+        V3 n = sf.normal;
+        if (dot(n, rayDirection) > 0.0f) n = -n;
+        const V3 R = normalize(lr.L - 2 * dot(lr.L, n) * n);
+        const float a = max0(dot(n, lr.L)), dr = max0(dot(rayDirection, R));
+        if (!(dr == 0.0f && sf.specularity > 0.0f)) return false;
+        c = 1.0f / (lr.dist * lr.dist) * lr.colour * (sf.diffuse * a + sf.specular * 0.0f);
+    }
+    const bool zero = c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
+    const bool plain = !(__float_as_uint(sf.diffuse.x) >> 31) && !(__float_as_uint(sf.diffuse.y) >> 31) &&
+                       !(__float_as_uint(sf.diffuse.z) >> 31);
+    return zero && plain;
+}
 // raytracer_fs.glsl:361-366: the reflected ray
 __device__ __forceinline__ V3 mirror_direction(const Surface& sf, V3 rayDirection) {
     V3 n = sf.normal;

@@ -269,20 +269,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_
     wf_run(g, a.counters + 4 * a.iter + 1, wf_active_count(a), job);
 }
 
-// pure flag + "diffuse is not black" of the winning hit (what ObjectInWayOfLight's callers branch on)
-__device__ __forceinline__ void wf_material_flags(const DevScene& S, int kind, int index, bool* pure, bool* diffuse_nz) {
-    const unsigned char* rec;
-    if (kind == 0)
-        rec = S.spheres_aos + (size_t)S.sphere_slot_id[index] * 48 + 16;
-    else if (kind == 1)
-        rec = S.planes_aos + (size_t)index * 64 + 32;
-    else
-        rec = S.tris_aos + (size_t)S.tri_slot_id[index] * 96 + 64;
-    const float4 m0 = *(const float4*)rec;
-    *pure = __float_as_uint(m0.w) != 0u;
-    *diffuse_nz = m0.x != 0 || m0.y != 0 || m0.z != 0;
-}
-
 // ------------------------------------------------------------------------------------------
 // shadow rays of every active path (ObjectInWayOfLight, raytracer_fs.glsl:200-240)
 // Work items are ordered (group of 64 consecutive active paths, light, path in group): the lanes
@@ -339,14 +325,26 @@ struct WfAnyJob {
         const uint32_t hit = __float_as_uint(q1.w);
         const int kind = (int)(hit >> 28), index = (int)(hit & 0xFFFFFF);
         if (kind == 3) return false;
-        bool pure, diffuse_nz;
-        wf_material_flags(S, kind, index, &pure, &diffuse_nz);
+        const V3 rayOrigin = v3(q0.x, q0.y, q0.z), rayDirection = v3(q1.x, q1.y, q1.z);
+        const V3 hitPos = rayOrigin + q0.w * rayDirection;
+        Closest h;
+        h.t = q0.w, h.kind = kind, h.index = index, h.n = v3(0, 0, 0);
+        if (kind == 0) {  // as k_wf_shade forms it
+            const float4 sp = S.geom[S.sph_off + index];
+            h.n = normalize(hitPos - v3(sp.x, sp.y, sp.z));
+        }
+        const Surface sf = resolve_surface(S, h);
+        const bool mirror = sf.pure && a.iter < a.max_bounces;
         // a mirror bounce only casts shadow rays for a non-black diffuse (raytracer_fs.glsl:340)
-        if (pure && a.iter < a.max_bounces && !diffuse_nz) return false;
-        const V3 hitPos = v3(q0.x, q0.y, q0.z) + q0.w * v3(q1.x, q1.y, q1.z);
+        if (mirror && !(sf.diffuse.x != 0 || sf.diffuse.y != 0 || sf.diffuse.z != 0)) return false;
         const LightRay lr = light_ray(S, (int)l, hitPos);
         o = hitPos, d = lr.L, dist = lr.dist;
         item = j * L + l;
+        if (light_term_is_zero(sf, mirror, rayDirection, lr)) {  // shaded as if blocked: the term adds nothing
+            blocked = true;
+            finish();
+            return false;
+        }
         br = make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
         blocked = false;
         for (int q = 0; q < S.n_planes && !blocked; q++) {
