@@ -354,19 +354,6 @@ __device__ __forceinline__ LightRay light_ray(const DevScene& S, int l, V3 hitPo
     r.colour = v3(q[3], q[4], q[5]);
     return r;
 }
-// raytracer_fs.glsl:342-357: a mirror with a diffuse component (the normal is not flipped here).
-// in_shadow(l, lightRay) is the caller's ObjectInWayOfLight (traced inline, or read back from the
-// any-hit stage of the wavefront pipeline).
-template <class Shadow>
-__device__ __forceinline__ V3 mirror_diffuse_term(const DevScene& S, const Surface& sf, V3 hitPos, Shadow&& in_shadow) {
-    V3 combined = sf.diffuse * v3(0.1f, 0.1f, 0.1f);
-    for (int l = 0; l < S.lights_len / 6; l++) {
-        const LightRay lr = light_ray(S, l, hitPos);
-        if (!in_shadow(l, lr))
-            combined = combined + 1.0f / (lr.dist * lr.dist) * lr.colour * sf.diffuse * max0(dot(sf.normal, lr.L));
-    }
-    return combined;
-}
 // Would this light's term of mirror_diffuse_term (mirror) / phong_term add exactly nothing, whatever its
 // shadow ray finds?  Same expressions as those two functions, so the same values: the term is
 // c = 1/d^2 * colour * (diffuse * max0(n.L) [+ specular * pow(max0(D.R), specularity)]), and
@@ -391,6 +378,19 @@ __device__ __forceinline__ bool light_term_is_zero(const Surface& sf, bool mirro
     const bool plain = !(__float_as_uint(sf.diffuse.x) >> 31) && !(__float_as_uint(sf.diffuse.y) >> 31) &&
                        !(__float_as_uint(sf.diffuse.z) >> 31);
     return zero && plain;
+}
+// raytracer_fs.glsl:342-357: a mirror with a diffuse component (the normal is not flipped here).
+// in_shadow(l, lightRay) is the caller's ObjectInWayOfLight (traced inline, or read back from the
+// any-hit stage of the wavefront pipeline).
+template <class Shadow>
+__device__ __forceinline__ V3 mirror_diffuse_term(const DevScene& S, const Surface& sf, V3 hitPos, Shadow&& in_shadow) {
+    V3 combined = sf.diffuse * v3(0.1f, 0.1f, 0.1f);
+    for (int l = 0; l < S.lights_len / 6; l++) {
+        const LightRay lr = light_ray(S, l, hitPos);
+        if (!in_shadow(l, lr))
+            combined = combined + 1.0f / (lr.dist * lr.dist) * lr.colour * sf.diffuse * max0(dot(sf.normal, lr.L));
+    }
+    return combined;
 }
 // raytracer_fs.glsl:361-366: the reflected ray
 __device__ __forceinline__ V3 mirror_direction(const Surface& sf, V3 rayDirection) {
@@ -446,7 +446,9 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
         if (REF) cnt[C_SECONDARY]++;
         const V3 hitPos = rayOrigin + h.t * rayDirection;
         if (sf.diffuse.x != 0 || sf.diffuse.y != 0 || sf.diffuse.z != 0) {
+            // fast kernels: a light whose term is exactly zero either way needs no shadow ray
             const V3 combined = mirror_diffuse_term(S, sf, hitPos, [&](int, const LightRay& lr) {
+                if (!REF && light_term_is_zero(sf, true, rayDirection, lr)) return true;
                 return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt);
             });
             finalColor = finalColor + combined * mult;
@@ -467,6 +469,7 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
     }
     const V3 hitPos = rayOrigin + h.t * rayDirection;
     const V3 combined = phong_term(S, sf, hitPos, rayDirection, [&](int, const LightRay& lr) {
+        if (!REF && light_term_is_zero(sf, false, rayDirection, lr)) return true;
         return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt);
     });
     out.rgb = finalColor + combined * mult;

@@ -297,3 +297,36 @@ def test_the_table_models_collinear_triangles_are_marked(rt_mode, scene_of):
     assert info["flags"] == 3 and info["unbounded_triangles"] == 19
     rt.SendPrimitivesToShader(scene_of("TeapotScene"))
     assert rt.scene_info()["unbounded_triangles"] == 0
+
+
+@pytest.mark.parametrize("mode,label", MODES, ids=[m[1] for m in MODES])
+def test_untraced_shadow_rays_leave_every_float_as_it_was(mode, label, rt_mode, scene_of):
+    """The fast kernels do not trace a shadow ray when the light's term is exactly zero whichever way
+    the ray ends.  That must hold bit for bit, also where zero is delicate: negative-zero and negative
+    diffuse colours, negative light colours, black speculars, specularity 0 (pow(0, 0) = 1) -- compared
+    float for float with the reference-order kernel, which traces everything."""
+    rt = rt_mode
+    sc = scene_of("Soup", [6000, 60, 8])
+    g = np.random.default_rng(17)
+    tri, sph, pl = sc.trianglesData.copy(), sc.spheresData.copy(), sc.planesData.copy()
+    for rec in (tri, sph):
+        n = len(rec)
+        pick = g.integers(0, 6, n)
+        rec["DiffuseColor"][pick == 0] = -0.0
+        rec["DiffuseColor"][pick == 1] *= -1.0
+        rec["DiffuseColor"][pick == 2] = 0.0
+        rec["SpecularColor"][g.integers(0, 4, n) == 0] = 0.0
+        rec["Specularity"][g.integers(0, 5, n) == 0] = 0.0
+    pl["DiffuseColor"] = -0.0
+    lights = sc.lightsData.copy().reshape(-1, 6)
+    lights[1, 3:] *= -1.0
+    lights[2, 3:] = 0.0
+    odd = Scene(sph, pl, tri, sc.AccelerationStructureData, lights.ravel(), sc.cameraData)
+    cam = odd.camera_for(256, 144)
+    want = ("rgb", "primary_id", "final_id")
+    slow = _render(rt, odd, cam, 4, want=want, stats=True)
+    _set_mode(rt, mode)
+    fast = _render(rt, odd, cam, 4, want=want)
+    assert np.array_equal(fast["primary_id"], slow["primary_id"]) and np.array_equal(fast["final_id"], slow["final_id"])
+    assert np.array_equal(fast["rgb"].view(np.uint32), slow["rgb"].view(np.uint32))
+    assert_frame_matches(fast, oracle_render(odd, cam, 4, threads=16), "odd materials " + label)
