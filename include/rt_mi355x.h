@@ -81,7 +81,7 @@ enum {
     RT_OPTION_TRAVERSAL = 3, /* RT_TRAVERSAL_*: which fast kernel renders (default AUTO: by scene size) */
     RT_OPTION_TIGHT_TREE = 4, /* 1 (default): uploads of large scenes also build a per-primitive tree that the
                                 staged pipeline walks as a filter in front of the reference's leaf-box rule
-                                (64 B per primitive, ~1 s of host time per million); 0: neither built nor used */
+                                (64 B per primitive, ~0.25 s of host time per million); 0: neither built nor used */
     RT_OPTION_WAVEFRONT_MIN_NODES = 5 /* "large scene" threshold in flattened node records (default 30000):
                                 from it on AUTO picks RT_TRAVERSAL_WAVEFRONT and uploads build the tight tree */
 };

@@ -18,7 +18,7 @@ DEVICE_LIB = os.path.join(HERE, "librt_mi355x.so")
 HOST_LIB = os.path.join(HERE, "librt_host.so")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-fno-fast-math",
              "-Wall", "-Wno-bitwise-instead-of-logical"]
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-bitwise-instead-of-logical"]

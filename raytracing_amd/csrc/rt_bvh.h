@@ -23,8 +23,10 @@
 // traversal always starts with `cur = 0`.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "rt_flatten.h"
@@ -85,10 +87,14 @@ struct Box {
 struct Builder {
     std::vector<Item>& items;
     Bvh& out;
+    std::atomic<int> levels{0};
     static constexpr int BINS = 16;
+    static constexpr size_t FORK_MIN = 1 << 15;  // subtrees at least this large may be built by another thread
 
-    // builds items[b, e), returns its ref and box; `room` = inner levels still available
-    uint32_t build(size_t b, size_t e, int level, Box* box) {
+    // Builds items[b, e) and returns its ref and box.  A subtree over m items has exactly m - 1 inner
+    // nodes: it owns out.nodes[base, base + m - 1) (root first, then the left subtree, then the right), so
+    // the layout does not depend on which thread builds what.  forks = thread forks still allowed below.
+    uint32_t build(size_t b, size_t e, int level, Box* box, uint32_t base, int forks) {
         box->reset();
         if (e - b == 1) {
             box->grow(items[b].lo, items[b].hi);
@@ -161,12 +167,20 @@ struct Builder {
             std::nth_element(items.begin() + b, items.begin() + mid, items.begin() + e,
                              [ax](const Item& x, const Item& y) { return x.lo[ax] + x.hi[ax] < y.lo[ax] + y.hi[ax]; });
         }
-        const uint32_t me = (uint32_t)out.nodes.size();
-        out.nodes.emplace_back();
-        if (level + 1 > out.levels) out.levels = level + 1;
+        const uint32_t me = base;
+        for (int seen = levels.load(); level + 1 > seen && !levels.compare_exchange_weak(seen, level + 1);) {
+        }
         Box l, r;
-        const uint32_t rl = build(b, mid, level + 1, &l);
-        const uint32_t rr = build(mid, e, level + 1, &r);
+        uint32_t rl, rr;
+        const uint32_t right_base = base + (uint32_t)(mid - b);  // 1 for this node + (mid - b - 1) of the left subtree
+        if (forks > 0 && n >= FORK_MIN) {
+            std::thread left([&] { rl = build(b, mid, level + 1, &l, base + 1, forks - 1); });
+            rr = build(mid, e, level + 1, &r, right_base, forks - 1);
+            left.join();
+        } else {
+            rl = build(b, mid, level + 1, &l, base + 1, 0);
+            rr = build(mid, e, level + 1, &r, right_base, 0);
+        }
         Node& nd = out.nodes[me];
         for (int k = 0; k < 3; k++) nd.lo0[k] = l.lo[k], nd.hi0[k] = l.hi[k], nd.lo1[k] = r.lo[k], nd.hi1[k] = r.hi[k];
         nd.ref0 = rl, nd.ref1 = rr, nd.pad0 = nd.pad1 = 0;
@@ -191,17 +205,18 @@ inline void build_items(std::vector<Item>& items, size_t split, Bvh* out) {
     out->levels = 0;
     out->leaves = (int64_t)items.size();
     if (items.empty()) return;
-    out->nodes.reserve(items.size() + 1);
-    out->nodes.emplace_back();  // node 0: root holder
-    out->levels = 1;
+    const size_t n_a = split, n_b = items.size() - split;
+    out->nodes.assign(1 + (n_a ? n_a - 1 : 0) + (n_b ? n_b - 1 : 0), Node{});  // node 0: root holder
     Builder bld{items, *out};
+    bld.levels = 1;
     Box box[2];
     uint32_t ref[2] = {LEAF, LEAF};  // empty leaf (count 0): harmless even if its box were accepted
     for (int h = 0; h < 2; h++) {
         const size_t b = h ? split : 0, e = h ? items.size() : split;
         box[h].reset();  // inverted: rejected by any finite ray
-        if (e > b) ref[h] = bld.build(b, e, 1, &box[h]);
+        if (e > b) ref[h] = bld.build(b, e, 1, &box[h], (uint32_t)(h ? 1 + (n_a ? n_a - 1 : 0) : 1), 4);
     }
+    out->levels = bld.levels.load();
     Node& h = out->nodes[0];
     for (int k = 0; k < 3; k++) {
         h.lo0[k] = box[0].lo[k], h.hi0[k] = box[0].hi[k];
