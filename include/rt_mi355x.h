@@ -183,6 +183,12 @@ int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out);
  * (raytracer_fs.glsl:65-68, 173-195). */
 int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_triangles, rt_scene_info* info,
                    char* err, size_t err_cap);
+/* The same with the primitives: everything rt_upload_scene decides on the host (cull preconditions ->
+ * flags, unbounded_triangles, the re-treed leaves, the tight tree for scenes of at least tight_min_nodes
+ * flattened nodes), followed by a structural self-check of both trees (exact unions, every slot reached
+ * once, depth bound, tight boxes contain their primitive's accepted region + pad).  No context, no GPU. */
+int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, int n_triangles, const float* accel,
+                   int64_t accel_len, int tight_min_nodes, rt_scene_info* info, char* err, size_t err_cap);
 
 /* Per-function device evaluators of the four intersection routines, one case per element
  * (raytracer_fs.glsl:134-161, 93-113, 114-120, 121-131).  Host arrays; used by the parity

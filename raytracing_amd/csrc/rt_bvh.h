@@ -336,10 +336,10 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
                 for (int v = 1; v < 3; v++) {
                     const double e[3] = {(double)r[4 * v] - r[0], (double)r[4 * v + 1] - r[1], (double)r[4 * v + 2] - r[2]};
                     // projection along N onto the plane through A; a zero or NaN normal never yields a hit
-                    double s = (e[0] * n[0] + e[1] * n[1] + e[2] * n[2]) / nn;
-                    if (!(nn > 0) || !(s == s)) s = 0;
+                    const double s = (e[0] * n[0] + e[1] * n[1] + e[2] * n[2]) / nn;
+                    const bool project = nn > 0 && s == s;
                     for (int c = 0; c < 3; c++) {
-                        const double x = (double)r[4 * v + c] - s * n[c];
+                        const double x = project ? (double)r[4 * v + c] - s * n[c] : (double)r[4 * v + c];
                         lo[c] = std::min(lo[c], x), hi[c] = std::max(hi[c], x);
                     }
                 }

@@ -12,6 +12,7 @@
 
 #include "rt_bvh.h"
 #include "rt_kernels.h"
+#include "rt_scene_prep.h"
 #include "rt_wavefront.h"
 
 using namespace rtd;
@@ -315,10 +316,28 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->has_scene = false;
 
-    rtf::Flat flat;
+    // everything decided on the host (rt_scene_prep.h): validation, cull preconditions, both trees
+    rtp::Prepared prep;
     std::string err;
-    int rc = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &flat, &err);
+    rtp::Options opt;
+    opt.build_tight = ctx->build_tight, opt.tight_min_nodes = ctx->wf_min_nodes;
+    int rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
+                          accel_len, opt, &prep, &err);
     if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
+    const rtf::Flat& flat = prep.flat;
+    const rtb::Bvh& bvh = prep.bvh;
+    rtb::Bvh& tight = prep.tight;
+    const std::vector<int32_t>&tri_slot_leaf = prep.tri_slot_leaf, &sphere_slot_leaf = prep.sphere_slot_leaf;
+    const bool contained = prep.contained;
+    const float* extent = prep.extent;
+    const float tight_e = prep.tight_e;
+    {  // the tight nodes follow the leaf tree's in one array: inner refs become indices of that array
+        const uint32_t base = (uint32_t)bvh.nodes.size();
+        for (rtb::Node& nd : tight.nodes) {
+            if (!(nd.ref0 & rtb::LEAF)) nd.ref0 += base;
+            if (!(nd.ref1 & rtb::LEAF)) nd.ref1 += base;
+        }
+    }
 
     if ((rc = upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48))) return rc;
     if ((rc = upload(ctx, ctx->planes_aos, planes, (size_t)n_planes * 64))) return rc;
@@ -328,107 +347,6 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     if ((rc = upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), flat.sphere_slot_id.size() * 4)))
         return rc;
     const int n_ts = (int)flat.tri_slot_id.size(), n_ss = (int)flat.sphere_slot_id.size();
-    float extent[3] = {0.0f, 0.0f, 0.0f};
-    if (!flat.nodes.empty()) {
-        const rtf::FlatNode& root = flat.nodes[0];
-        const float lo[3] = {root.minx, root.miny, root.minz}, hi[3] = {root.maxx, root.maxy, root.maxz};
-        for (int k = 0; k < 3; k++) extent[k] = std::fmax(std::fabs(lo[k]), std::fabs(hi[k]));
-    }
-
-    // distance cull precondition: boxes nested, every primitive inside its leaf box (within a slack
-    // far below the cull's pad), triangle normals perpendicular to their triangles; otherwise the
-    // kernels never cull
-    bool contained = flat.nested;
-    std::vector<uint8_t> tri_unbounded(flat.tri_slot_id.size(), 0);
-    std::vector<int32_t> unbounded_leaves;
-    if (contained) {
-        const float slack = std::fmax(extent[0], std::fmax(extent[1], extent[2])) * (1.0f / 4096.0f);
-        const unsigned char* T = (const unsigned char*)triangles;
-        const unsigned char* Sp = (const unsigned char*)spheres;
-        for (const rtf::FlatNode& fn : flat.nodes) {
-            const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = fn.meta & 0xFFFFFF;
-            if (kind == rtf::KIND_BRANCH) continue;
-            const float lo[3] = {fn.minx - slack, fn.miny - slack, fn.minz - slack};
-            const float hi[3] = {fn.maxx + slack, fn.maxy + slack, fn.maxz + slack};
-            for (int k = 0; k < count && contained; k++) {
-                if (kind == rtf::KIND_TRI) {
-                    const float* rec = (const float*)(T + (size_t)flat.tri_slot_id[first + k] * 96);
-                    for (int v = 0; v < 3; v++)
-                        for (int c = 0; c < 3; c++) {
-                            const float x = rec[4 * v + c];
-                            if (!(x >= lo[c] && x <= hi[c])) contained = false;
-                        }
-                    // the stored normal must be the triangle's: IntersectTriangle intersects the plane through
-                    // A with THAT normal, and the cull's proof needs the hit point on the triangle.  Measured
-                    // as the distance of B and C from that plane, allowed up to 1/8 of the cull's pad (the
-                    // reference's own sliver triangles reach 3e-3 rad, 0.003 units).  A NaN normal (zero-area
-                    // triangle, 32 of them in the teapot) or a zero normal never produces a hit and is fine.
-                    const float* n = rec + 12;
-                    const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
-                    for (int v = 1; v < 3 && nn == nn && nn > 0; v++) {
-                        const double off = std::fabs(((double)rec[4 * v] - rec[0]) * n[0] +
-                                                     ((double)rec[4 * v + 1] - rec[1]) * n[1] +
-                                                     ((double)rec[4 * v + 2] - rec[2]) * n[2]);
-                        if (!(off <= 4.0 * slack * nn)) contained = false;
-                    }
-                    // ... and the triangle must have an area as seen along that normal.  The three edge tests
-                    // accept the intersection of three half-planes; for collinear (projected) vertices that
-                    // is a whole line, for coincident vertices the whole plane: the reference then accepts
-                    // hits far outside any box around the vertices (they pass the leaf box test, which has
-                    // no distance bound).  Width/length below 1e-5 is within rounding of that case (the
-                    // reference's table model has 19 such triangles).  These are marked, not refused:
-                    // the distance cull leaves their subtrees alone (rtf::meta_nocull).
-                    if (nn == nn && nn > 0) {
-                        const double e1[3] = {(double)rec[4] - rec[0], (double)rec[5] - rec[1], (double)rec[6] - rec[2]};
-                        const double e2[3] = {(double)rec[8] - rec[0], (double)rec[9] - rec[1], (double)rec[10] - rec[2]};
-                        const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
-                        const double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2],
-                                              e1[0] * e2[1] - e1[1] * e2[0]};
-                        const double area2 = std::fabs(cr[0] * n[0] + cr[1] * n[1] + cr[2] * n[2]) / nn;
-                        const double len2 = std::max({e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2],
-                                                      e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2],
-                                                      e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]});
-                        if (!(area2 > 0) || !(area2 >= 1e-5 * len2)) {
-                            tri_unbounded[first + k] = 1;
-                            unbounded_leaves.push_back((int32_t)(&fn - flat.nodes.data()));
-                        }
-                    }
-                } else {
-                    const float* rec = (const float*)(Sp + (size_t)flat.sphere_slot_id[first + k] * 48);
-                    for (int c = 0; c < 3; c++)
-                        if (!(rec[c] - rec[3] >= lo[c] && rec[c] + rec[3] <= hi[c]) || !(rec[3] >= 0)) contained = false;
-                }
-            }
-            if (!contained) break;
-        }
-    }
-    if (contained)
-        for (int32_t leaf : unbounded_leaves) rtf::mark_unbounded(&flat, leaf);
-    // re-treed leaves for the per-lane kernels (only for nested trees, rt_bvh.h)
-    rtb::Bvh bvh;
-    if (flat.nested) rtb::build(flat, &bvh);
-
-    // tight per-primitive tree for the staged pipeline's rays (rt_bvh.h build_tight): large scenes
-    // whose primitives were just verified to sit inside their leaves with matching normals
-    rtb::Bvh tight;
-    std::vector<int32_t> tri_slot_leaf, sphere_slot_leaf;
-    const float max_extent = std::fmax(extent[0], std::fmax(extent[1], extent[2]));
-    const float tight_e = 4.0f * max_extent;  // origins up to 3 scene radii from the world origin
-    if (ctx->build_tight && contained && !bvh.nodes.empty() && (int)flat.nodes.size() >= ctx->wf_min_nodes &&
-        max_extent <= 1e6f) {
-        rtb::TightInput in;
-        in.tris = (const unsigned char*)triangles, in.spheres = (const unsigned char*)spheres;
-        in.pad_tri = tight_e * (1.0f / 16384.0f), in.pad_sphere = tight_e * (1.0f / 256.0f);
-        in.tri_unbounded = &tri_unbounded;
-        rtb::build_tight(flat, in, &tight, &tri_slot_leaf, &sphere_slot_leaf);
-        if (tight.levels > rtb::MAX_LEVELS) tight.nodes.clear();
-        // its nodes follow the leaf tree's in one array: inner refs become indices of that array
-        const uint32_t base = (uint32_t)bvh.nodes.size();
-        for (rtb::Node& nd : tight.nodes) {
-            if (!(nd.ref0 & rtb::LEAF)) nd.ref0 += base;
-            if (!(nd.ref1 & rtb::LEAF)) nd.ref1 += base;
-        }
-    }
     // one contiguous geometry image: nodes | triangle slots | sphere slots | BVH nodes (rt_device.h)
     const size_t tri_off = flat.nodes.size() * 2, sph_off = tri_off + (size_t)n_ts * 3;
     const size_t bvh_off = sph_off + (size_t)n_ss;
@@ -507,7 +425,7 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     inf.bvh_nodes = (int64_t)bvh.nodes.size();
     inf.bvh_levels = bvh.levels;
     inf.flags = (flat.nested ? RT_SCENE_NESTED : 0) | (contained ? RT_SCENE_CULL : 0);
-    inf.unbounded_triangles = contained ? (int64_t)std::count(tri_unbounded.begin(), tri_unbounded.end(), 1) : 0;
+    inf.unbounded_triangles = prep.unbounded;
     inf.device_bytes += (int64_t)(bvh.nodes.size() * sizeof(rtb::Node));
     inf.tight_nodes = (int64_t)tight.nodes.size();
     inf.tight_levels = tight.nodes.empty() ? 0 : tight.levels;
@@ -544,6 +462,48 @@ int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_t
             info->bvh_nodes = (int64_t)bvh.nodes.size();
             info->bvh_levels = bvh.levels;
         }
+    }
+    return rc;
+}
+
+int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, int n_triangles, const float* accel,
+                   int64_t accel_len, int tight_min_nodes, rt_scene_info* info, char* err, size_t err_cap) {
+    std::string msg;
+    int rc = RT_OK;
+    if (accel_len < 0 || n_spheres < 0 || n_triangles < 0 || tight_min_nodes < 0 || (accel_len && !accel) ||
+        (n_spheres && !spheres) || (n_triangles && !triangles)) {
+        rc = RT_ERR_INVALID_ARGUMENT;
+        msg = "negative size or null array";
+    }
+    rtp::Prepared prep;
+    if (rc == RT_OK) {
+        rtp::Options opt;
+        opt.tight_min_nodes = tight_min_nodes;
+        rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
+                          accel_len, opt, &prep, &msg);
+    }
+    if (rc == RT_OK) {
+        msg = rtp::verify_tree(prep.bvh, nullptr, nullptr, nullptr);
+        if (msg.empty())
+            msg = rtp::verify_tree(prep.tight, &prep, (const unsigned char*)spheres, (const unsigned char*)triangles);
+        if (!msg.empty()) rc = RT_ERR_DEVICE;  // an internal inconsistency, never expected
+    }
+    if (err && err_cap) {
+        std::strncpy(err, msg.c_str(), err_cap - 1);
+        err[err_cap - 1] = 0;
+    }
+    if (rc == RT_OK && info) {
+        std::memset(info, 0, sizeof *info);
+        info->n_nodes = (int64_t)prep.flat.nodes.size();
+        info->n_tri_slots = (int64_t)prep.flat.tri_slot_id.size();
+        info->n_sphere_slots = (int64_t)prep.flat.sphere_slot_id.size();
+        info->max_depth = prep.flat.max_depth;
+        info->flags = (prep.flat.nested ? RT_SCENE_NESTED : 0) | (prep.contained ? RT_SCENE_CULL : 0);
+        info->bvh_nodes = (int64_t)prep.bvh.nodes.size();
+        info->bvh_levels = prep.bvh.levels;
+        info->tight_nodes = (int64_t)prep.tight.nodes.size();
+        info->tight_levels = prep.tight.nodes.empty() ? 0 : prep.tight.levels;
+        info->unbounded_triangles = prep.unbounded;
     }
     return rc;
 }

@@ -1,0 +1,230 @@
+// rt_scene_prep.h -- everything rt_upload_scene decides on the host before a byte goes to the GPU:
+// flatten + validate the serialised R-tree, check the preconditions of the distance cull, mark the
+// triangles the reference accepts on a whole line or plane, build the re-treed leaves and (large
+// scenes) the tight tree.  No HIP in here: rt_check_scene runs the same code without a device, which
+// is what the CPU tests use.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rt_bvh.h"
+#include "rt_flatten.h"
+
+namespace rtp {
+
+struct Options {
+    bool build_tight = true;
+    int tight_min_nodes = 8000;  // flat node records from which a scene gets the tight tree
+};
+
+struct Prepared {
+    rtf::Flat flat;
+    rtb::Bvh bvh;    // re-treed leaves; empty if the tree is not nested
+    rtb::Bvh tight;  // per-primitive tree (inner refs relative to its own node 0); empty if not built
+    std::vector<int32_t> tri_slot_leaf, sphere_slot_leaf;  // slot -> reference leaf record (tight tree only)
+    std::vector<uint8_t> tri_unbounded;                    // per triangle slot (rtf::meta_nocull)
+    float extent[3] = {0, 0, 0};  // per-axis max |coordinate| of the root box
+    bool contained = false;       // nested + primitives inside their leaves + normals match: the cull is allowed
+    float tight_e = 0;            // E_build of the tight tree's pads
+    float pad_tri = 0, pad_sphere = 0;
+    int64_t unbounded = 0;
+};
+
+// Is a triangle record (TriangleStruct, 96 B: A|_ B|_ C|_ N|_ ...) accepted on a line or plane?  Its three
+// edge tests accept the intersection of three half-planes of the plane through A with the stored normal;
+// for vertices that are collinear or coincident as seen along that normal this is a whole line or the
+// whole plane, wherever the ray passes the leaf's box test (which has no distance bound).  Width/length
+// below 1e-5 is within rounding of that case (the reference's table model has 19 such triangles).
+// A NaN or zero normal never yields a hit and is not "unbounded".
+inline bool triangle_is_unbounded(const float* rec) {
+    const float* n = rec + 12;
+    const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+    if (!(nn == nn) || !(nn > 0)) return false;
+    const double e1[3] = {(double)rec[4] - rec[0], (double)rec[5] - rec[1], (double)rec[6] - rec[2]};
+    const double e2[3] = {(double)rec[8] - rec[0], (double)rec[9] - rec[1], (double)rec[10] - rec[2]};
+    const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
+    const double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double area2 = std::fabs(cr[0] * n[0] + cr[1] * n[1] + cr[2] * n[2]) / nn;
+    const double len2 = std::max({e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2],
+                                  e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]});
+    return !(area2 > 0) || !(area2 >= 1e-5 * len2);
+}
+
+// Distance cull precondition: boxes nested, every primitive inside its leaf box (within a slack far
+// below the cull's pad), stored triangle normals perpendicular to their triangles.  Also collects the
+// unbounded triangles.  Returns false if the cull must stay off.
+inline bool check_containment(const rtf::Flat& flat, const unsigned char* spheres, const unsigned char* triangles,
+                              const float extent[3], std::vector<uint8_t>* tri_unbounded,
+                              std::vector<int32_t>* unbounded_leaves) {
+    if (!flat.nested) return false;
+    const float slack = std::fmax(extent[0], std::fmax(extent[1], extent[2])) * (1.0f / 4096.0f);
+    for (size_t ni = 0; ni < flat.nodes.size(); ni++) {
+        const rtf::FlatNode& fn = flat.nodes[ni];
+        const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = fn.meta & 0xFFFFFF;
+        if (kind == rtf::KIND_BRANCH) continue;
+        const float lo[3] = {fn.minx - slack, fn.miny - slack, fn.minz - slack};
+        const float hi[3] = {fn.maxx + slack, fn.maxy + slack, fn.maxz + slack};
+        for (int k = 0; k < count; k++) {
+            if (kind == rtf::KIND_SPHERE) {
+                const float* rec = (const float*)(spheres + (size_t)flat.sphere_slot_id[first + k] * 48);
+                for (int c = 0; c < 3; c++)
+                    if (!(rec[c] - rec[3] >= lo[c] && rec[c] + rec[3] <= hi[c]) || !(rec[3] >= 0)) return false;
+                continue;
+            }
+            const float* rec = (const float*)(triangles + (size_t)flat.tri_slot_id[first + k] * 96);
+            for (int v = 0; v < 3; v++)
+                for (int c = 0; c < 3; c++) {
+                    const float x = rec[4 * v + c];
+                    if (!(x >= lo[c] && x <= hi[c])) return false;
+                }
+            // the stored normal must be the triangle's: IntersectTriangle intersects the plane through A
+            // with THAT normal, and the cull's proof needs the hit point on the triangle.  Measured as the
+            // distance of B and C from that plane, allowed up to 1/8 of the cull's pad (the reference's own
+            // sliver triangles reach 3e-3 rad, 0.003 units).  A NaN normal (zero-area triangle, 32 of them
+            // in the teapot) or a zero normal never produces a hit and is fine.
+            const float* n = rec + 12;
+            const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+            for (int v = 1; v < 3 && nn == nn && nn > 0; v++) {
+                const double off = std::fabs(((double)rec[4 * v] - rec[0]) * n[0] + ((double)rec[4 * v + 1] - rec[1]) * n[1] +
+                                             ((double)rec[4 * v + 2] - rec[2]) * n[2]);
+                if (!(off <= 4.0 * slack * nn)) return false;
+            }
+            if (triangle_is_unbounded(rec)) {
+                (*tri_unbounded)[first + k] = 1;
+                unbounded_leaves->push_back((int32_t)ni);
+            }
+        }
+    }
+    return true;
+}
+
+// Returns rtf::FLATTEN_* (0 = ok).  spheres / triangles: the uploaded SphereStruct / TriangleStruct arrays.
+inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned char* triangles, int n_triangles,
+                   const float* accel, int64_t accel_len, const Options& opt, Prepared* out, std::string* err) {
+    rtf::Flat& flat = out->flat;
+    const int rc = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &flat, err);
+    if (rc != rtf::FLATTEN_OK) return rc;
+    for (int k = 0; k < 3; k++) out->extent[k] = 0.0f;
+    if (!flat.nodes.empty()) {
+        const rtf::FlatNode& root = flat.nodes[0];
+        const float lo[3] = {root.minx, root.miny, root.minz}, hi[3] = {root.maxx, root.maxy, root.maxz};
+        for (int k = 0; k < 3; k++) out->extent[k] = std::fmax(std::fabs(lo[k]), std::fabs(hi[k]));
+    }
+    out->tri_unbounded.assign(flat.tri_slot_id.size(), 0);
+    std::vector<int32_t> unbounded_leaves;
+    out->contained = check_containment(flat, spheres, triangles, out->extent, &out->tri_unbounded, &unbounded_leaves);
+    if (!out->contained) std::fill(out->tri_unbounded.begin(), out->tri_unbounded.end(), 0);  // no cull: nothing to protect
+    out->unbounded = (int64_t)std::count(out->tri_unbounded.begin(), out->tri_unbounded.end(), 1);
+    if (out->contained)
+        for (int32_t leaf : unbounded_leaves) rtf::mark_unbounded(&flat, leaf);
+    // re-treed leaves for the per-lane kernels (only for nested trees, rt_bvh.h)
+    out->bvh = rtb::Bvh();
+    if (flat.nested) rtb::build(flat, &out->bvh);
+    // tight per-primitive tree for the staged pipeline's rays (rt_bvh.h build_tight): large scenes whose
+    // primitives were just verified to sit inside their leaves with matching normals
+    out->tight = rtb::Bvh();
+    out->tri_slot_leaf.clear(), out->sphere_slot_leaf.clear();
+    const float max_extent = std::fmax(out->extent[0], std::fmax(out->extent[1], out->extent[2]));
+    out->tight_e = 4.0f * max_extent;  // origins up to 3 scene radii from the world origin
+    out->pad_tri = out->tight_e * (1.0f / 16384.0f), out->pad_sphere = out->tight_e * (1.0f / 256.0f);
+    if (opt.build_tight && out->contained && !out->bvh.nodes.empty() && (int64_t)flat.nodes.size() >= opt.tight_min_nodes &&
+        max_extent <= 1e6f) {
+        rtb::TightInput in;
+        in.tris = triangles, in.spheres = spheres;
+        in.pad_tri = out->pad_tri, in.pad_sphere = out->pad_sphere;
+        in.tri_unbounded = &out->tri_unbounded;
+        rtb::build_tight(flat, in, &out->tight, &out->tri_slot_leaf, &out->sphere_slot_leaf);
+        if (out->tight.levels > rtb::MAX_LEVELS) out->tight = rtb::Bvh();
+    }
+    return rtf::FLATTEN_OK;
+}
+
+// Structural self-check of a tree built by rt_bvh.h (used by rt_check_scene, i.e. by the CPU tests):
+// every inner box is the exact min/max union of its children, every leaf ref is reached exactly once,
+// the depth bound holds, never-cull marks are present exactly above kind-3 leaves.  For the tight tree
+// also: each primitive's accepted region (A, B', C' / the sphere) lies inside its leaf box shrunk by the
+// pad.  Returns an empty string or a description of the first violation.
+inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, const unsigned char* spheres,
+                               const unsigned char* triangles) {
+    if (t.nodes.empty()) return "";
+    std::vector<uint8_t> seen_tri, seen_sph;
+    if (tight_of) seen_tri.assign(tight_of->flat.tri_slot_id.size(), 0), seen_sph.assign(tight_of->flat.sphere_slot_id.size(), 0);
+    struct Todo {
+        uint32_t ref;
+        float lo[3], hi[3];
+        int level;
+    };
+    std::vector<Todo> stack;
+    auto push = [&](uint32_t ref, const float* lo, const float* hi, int level) {
+        Todo td;
+        td.ref = ref, td.level = level;
+        for (int k = 0; k < 3; k++) td.lo[k] = lo[k], td.hi[k] = hi[k];
+        stack.push_back(td);
+    };
+    const rtb::Node& h = t.nodes[0];
+    push(h.ref0, h.lo0, h.hi0, 1);
+    push(h.ref1, h.lo1, h.hi1, 1);
+    size_t visited = 1;
+    while (!stack.empty()) {
+        const Todo td = stack.back();
+        stack.pop_back();
+        if (td.ref & rtb::LEAF) {
+            const int kind = (td.ref >> 29) & 3, count = (td.ref >> 24) & 31, first = (int)(td.ref & 0xFFFFFF);
+            if (!tight_of || count == 0) continue;
+            if (count != 1) return "tight leaf with more than one slot";
+            if (kind == rtf::KIND_SPHERE) {
+                if (seen_sph[first]++) return "sphere slot reached twice";
+                const float* rec = (const float*)(spheres + (size_t)tight_of->flat.sphere_slot_id[first] * 48);
+                for (int c = 0; c < 3; c++)
+                    if (!((double)rec[c] - rec[3] - tight_of->pad_sphere >= td.lo[c] - 1e-6 * std::fabs(td.lo[c]) &&
+                          (double)rec[c] + rec[3] + tight_of->pad_sphere <= td.hi[c] + 1e-6 * std::fabs(td.hi[c])))
+                        return "sphere sticks out of its padded tight box";
+            } else {
+                if (seen_tri[first]++) return "triangle slot reached twice";
+                if (tight_of->tri_unbounded[first]) {
+                    if (kind != rtf::KIND_TRI_UNBOUNDED || td.lo[0] > -3e38f || td.hi[0] < 3e38f) return "unbounded triangle in a finite box";
+                    continue;
+                }
+                const float* rec = (const float*)(triangles + (size_t)tight_of->flat.tri_slot_id[first] * 96);
+                const double n[3] = {rec[12], rec[13], rec[14]};
+                const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                for (int v = 0; v < 3; v++) {  // A, B', C': the region IntersectTriangle accepts (rt_bvh.h)
+                    const double e[3] = {(double)rec[4 * v] - rec[0], (double)rec[4 * v + 1] - rec[1], (double)rec[4 * v + 2] - rec[2]};
+                    const double sc = (e[0] * n[0] + e[1] * n[1] + e[2] * n[2]) / nn;
+                    const bool project = nn > 0 && sc == sc;
+                    for (int c = 0; c < 3; c++) {
+                        const double x = project ? (double)rec[4 * v + c] - sc * n[c] : (double)rec[4 * v + c];
+                        if (!(x - tight_of->pad_tri >= td.lo[c] - 1e-6 * std::fabs(td.lo[c]) &&
+                              x + tight_of->pad_tri <= td.hi[c] + 1e-6 * std::fabs(td.hi[c])))
+                            return "triangle region sticks out of its padded tight box";
+                    }
+                }
+            }
+            continue;
+        }
+        const uint32_t idx = td.ref & rtb::INDEX_MASK;
+        if (idx == 0 || idx >= t.nodes.size()) return "inner ref out of range";
+        if (td.level + 1 > rtb::MAX_LEVELS || td.level + 1 > t.levels) return "deeper than the recorded level count";
+        visited++;
+        const rtb::Node& nd = t.nodes[idx];
+        for (int k = 0; k < 3; k++)
+            if (std::fmin(nd.lo0[k], nd.lo1[k]) != td.lo[k] || std::fmax(nd.hi0[k], nd.hi1[k]) != td.hi[k])
+                return "inner box is not the exact union of its children";
+        if (rtb::ref_nocull(td.ref) != (rtb::ref_nocull(nd.ref0) || rtb::ref_nocull(nd.ref1))) return "never-cull mark not propagated";
+        push(nd.ref0, nd.lo0, nd.hi0, td.level + 1);
+        push(nd.ref1, nd.lo1, nd.hi1, td.level + 1);
+    }
+    if (visited != t.nodes.size()) return "unreachable or shared nodes";
+    if (tight_of) {
+        for (uint8_t s : seen_tri)
+            if (s != 1) return "triangle slot missing from the tight tree";
+        for (uint8_t s : seen_sph)
+            if (s != 1) return "sphere slot missing from the tight tree";
+    }
+    return "";
+}
+
+}  // namespace rtp

@@ -37,6 +37,20 @@ def check_accel(accel, n_spheres, n_triangles):
     return {n: int(getattr(info, n)) for n, _ in N.rt_scene_info._fields_ if n != "reserved"}
 
 
+def check_scene(scene, tight_min_nodes=8000):
+    """rt_check_scene: the host half of rt_upload_scene (validation, cull preconditions, both trees) plus a
+    structural self-check of the trees.  Returns the scene info or raises RtError (no GPU needed)."""
+    lib = N.device_lib()
+    info = N.rt_scene_info()
+    err = C.create_string_buffer(256)
+    sp, tr, a = scene.spheresData, scene.trianglesData, scene.AccelerationStructureData
+    rc = lib.rt_check_scene(N.ptr(sp) if len(sp) else None, len(sp), N.ptr(tr) if len(tr) else None, len(tr),
+                            N.ptr(a) if len(a) else None, len(a), int(tight_min_nodes), C.byref(info), err, 256)
+    if rc != 0:
+        raise RtError(rc, err.value.decode())
+    return {n: int(getattr(info, n)) for n, _ in N.rt_scene_info._fields_ if n != "reserved"}
+
+
 class RayTracer:
     def __init__(self, device_id=0):
         self._lib = N.device_lib()
