@@ -135,6 +135,18 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
                      int rank, int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id,
                      int32_t* d_final_id, int32_t* d_bounces, rt_stats* d_stats, void* stream);
 
+/* Batch form of rt_render_device for hosts that render several small frames per step (one rank of a
+ * band-sharded multi-GPU render gets 1/world of every frame: a launch per frame would be latency bound).
+ * cameras: n_frames x 14 floats (host), all of one width/height; frame f's pixels start
+ * f * frame_stride PIXELS after frame 0's in every output plane (frame_stride >= rt_local_rows() * W).
+ * The megakernels render up to 8 frames per launch; large scenes (RT_TRAVERSAL_WAVEFRONT), the LDS
+ * kernel and RT_RENDER_REFERENCE_ORDER take one launch (sequence) per frame.  Results are those of
+ * n_frames rt_render_device calls.  No counterpart in the reference (one frame per draw). */
+int rt_render_frames_device(rt_ctx* ctx, const float* cameras, int n_frames, int max_bounces, int flags,
+                            int band_rows, int rank, int world, int64_t frame_stride, float* d_rgb,
+                            uint8_t* d_rgba8, int32_t* d_primary_id, int32_t* d_final_id, int32_t* d_bounces,
+                            void* stream);
+
 /* Number of rows rank renders (see rt_render_device), and the padded per-rank row count that
  * makes every rank's contribution equal-sized for a gather. */
 int rt_local_rows(int height, int band_rows, int rank, int world);

@@ -483,9 +483,14 @@ __device__ __forceinline__ uint32_t quantise(float v) {
     return (uint32_t)rintf(v * 255.0f);
 }
 
+constexpr int MAX_BATCH = 8;  // frames one launch of the megakernels can render (rt_render_frames_device)
 struct RenderArgs {
     DevScene scene;
-    float cam[14];
+    float cam[14];                      // frame 0
+    float more_cams[MAX_BATCH - 1][14];  // frames 1 .. n_frames-1 of a batched launch
+    int n_frames;                       // blocks [f * blocks_per_frame, (f+1) * blocks_per_frame) render frame f
+    int blocks_per_frame;
+    unsigned long long frame_stride;    // pixels between consecutive frames in every output plane
     int max_bounces;
     int width, height;   // full frame
     int local_rows;      // rows this launch renders
@@ -502,8 +507,28 @@ struct RenderArgs {
     unsigned int ticket_base;
 };
 
-__device__ __forceinline__ void store_pixel(const RenderArgs& a, int x, int r, const PixelOut& p) {
-    const size_t i = (size_t)r * a.width + x;
+// Which frame of a batched launch does this workgroup render?  Everything here is wave-uniform (scalar):
+// the camera is picked with compile-time indices only (a dynamic index into the by-value argument struct
+// would send the whole struct to scratch memory).  Returns the frame; *block becomes the block index
+// inside the frame.
+__device__ __forceinline__ int select_frame(const RenderArgs& a, int* block, float cam[14]) {
+    int f = 0;
+    if (a.n_frames > 1) {
+        f = *block / a.blocks_per_frame;
+        *block -= f * a.blocks_per_frame;
+    }
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        float v = a.cam[k];
+#pragma unroll
+        for (int q = 1; q < MAX_BATCH; q++) v = (f == q) ? a.more_cams[q - 1][k] : v;
+        cam[k] = v;
+    }
+    return f;
+}
+
+__device__ __forceinline__ void store_pixel(const RenderArgs& a, int frame, int x, int r, const PixelOut& p) {
+    const size_t i = (size_t)frame * a.frame_stride + (size_t)r * a.width + x;
     if (a.rgb) a.rgb[3 * i] = p.rgb.x, a.rgb[3 * i + 1] = p.rgb.y, a.rgb[3 * i + 2] = p.rgb.z;
     if (a.rgba8) a.rgba8[i] = quantise(p.rgb.x) | (quantise(p.rgb.y) << 8) | (quantise(p.rgb.z) << 16) | 0xFF000000u;
     if (a.primary_id) a.primary_id[i] = p.primary_id;
@@ -548,8 +573,10 @@ static_assert(BLOCK_WAVES == 1 || BLOCK_WAVES == 2 || BLOCK_WAVES == 4, "1, 2 or
 // ---- geometry in HBM/L2: one thread per pixel, one 16x16 tile per workgroup -------------------
 template <bool REF>
 __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a) {
-    int tx, ty;
-    const bool in_image = block_to_tile(blockIdx.x, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
+    int tx, ty, block = blockIdx.x;
+    float cam[14];
+    const int frame = select_frame(a, &block, cam);
+    const bool in_image = block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
     const int r = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);  // local row
@@ -566,12 +593,12 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
 #endif
     if (live) {
-        const PixelOut p = shade_pixel<REF>(a.scene, g, a.cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, cnt);
-        store_pixel(a, x, r, p);
+        const PixelOut p = shade_pixel<REF>(a.scene, g, cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, cnt);
+        store_pixel(a, frame, x, r, p);
     }
 #ifdef RT_DIAG_WAVE_CYCLES
     if (!REF && live && a.bounces)
-        a.bounces[(size_t)r * a.width + x] = (int32_t)(__builtin_amdgcn_s_memtime() - diag_t0);
+        a.bounces[(size_t)frame * a.frame_stride + (size_t)r * a.width + x] = (int32_t)(__builtin_amdgcn_s_memtime() - diag_t0);
 #endif
     if (REF && a.stats) {
 #pragma unroll
@@ -592,8 +619,10 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 template <bool UNB>
 __global__ __launch_bounds__(64 * BLOCK_WAVES) __attribute__((amdgpu_waves_per_eu(RT_BVH_WAVES_PER_EU, 8))) void k_render_bvh(
     const RenderArgs a) {
-    int tx, ty;
-    const bool in_image = block_to_tile(blockIdx.x, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
+    int tx, ty, block = blockIdx.x;
+    float cam[14];
+    const int frame = select_frame(a, &block, cam);
+    const bool in_image = block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
     const int r = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);
@@ -607,8 +636,8 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) __attribute__((amdgpu_waves_per_e
 #endif
     if (live) {
         const PixelOut p =
-            shade_pixel<false>(a.scene, g, a.cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, nullptr);
-        store_pixel(a, x, r, p);
+            shade_pixel<false>(a.scene, g, cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, nullptr);
+        store_pixel(a, frame, x, r, p);
 #ifdef RT_DIAG_STEPS  // planes receive: bounces <- node steps, final_id <- primitive tests, primary_id <- wave
                       // iterations (node << 16 | leaf) credited to the first active lane, rgb.x <- unused
         const size_t i = (size_t)r * a.width + x;
@@ -658,7 +687,7 @@ __global__ __launch_bounds__(LDS_BLOCK) void k_render_bvh_lds(const RenderArgs a
             const int y = global_row(a, r);
             const PixelOut p =
                 shade_pixel<false>(a.scene, g, a.cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, nullptr);
-            store_pixel(a, x, r, p);
+            store_pixel(a, 0, x, r, p);
         }
     }
 }

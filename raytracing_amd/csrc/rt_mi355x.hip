@@ -516,9 +516,13 @@ int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out) {
     return RT_OK;
 }
 
-int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int flags, int band_rows, int rank,
-                     int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id, int32_t* d_final_id,
-                     int32_t* d_bounces, rt_stats* d_stats, void* stream) {
+// Core of rt_render_device / rt_render_frames_device: n_frames (<= MAX_BATCH) cameras of one size in one
+// launch of a megakernel; the staged pipeline, the LDS kernel and the reference-order kernel take one
+// frame per launch (callers loop).
+static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_t frame_stride, int max_bounces,
+                         int flags, int band_rows, int rank, int world, float* d_rgb, uint8_t* d_rgba8,
+                         int32_t* d_primary_id, int32_t* d_final_id, int32_t* d_bounces, rt_stats* d_stats,
+                         void* stream) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_upload_scene has not succeeded on this context");
     int w, h;
@@ -529,9 +533,16 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
     if (((uintptr_t)d_rgba8 & 3) != 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "d_rgba8 must be 4-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
+    for (int f = 1; f < n_frames; f++)
+        if (camera[14 * f + 12] != camera[12] || camera[14 * f + 13] != camera[13])
+            return fail(ctx, RT_ERR_INVALID_ARGUMENT, "the frames of one batch must have one size");
     RenderArgs a;
     a.scene = ctx->scene;
     std::memcpy(a.cam, camera, sizeof a.cam);
+    std::memset(a.more_cams, 0, sizeof a.more_cams);
+    for (int f = 1; f < n_frames; f++) std::memcpy(a.more_cams[f - 1], camera + 14 * f, sizeof a.cam);
+    a.n_frames = n_frames;
+    a.frame_stride = frame_stride;
     a.max_bounces = max_bounces;
     a.width = w, a.height = h;
     a.local_rows = rt_local_rows(h, band_rows, rank, world);
@@ -542,6 +553,7 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
     // grid: whole super-tiles, their count padded to a multiple of the 8 XCD slots
     const int n_super = ((a.tiles_x + a.supertile - 1) / a.supertile) * ((a.tiles_y + a.supertile - 1) / a.supertile);
     const int n_blocks = ((n_super + 7) / 8) * 8 * a.supertile * a.supertile;
+    a.blocks_per_frame = n_blocks;
     a.rgb = d_rgb;
     a.rgba8 = (uint32_t*)d_rgba8;
     a.primary_id = d_primary_id;
@@ -558,11 +570,24 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
         (size_t)((w + 7) / 8) * ((a.local_rows + 7) / 8) * 64 * (size_t)std::max(a.scene.lights_len / 6, 1) >= 0xFFFFFFF0ull)
         trav = RT_TRAVERSAL_BVH;
     const bool use_wf = trav == RT_TRAVERSAL_WAVEFRONT, use_bvh = trav == RT_TRAVERSAL_BVH;
+    const bool use_lds = use_bvh && !(flags & RT_RENDER_GLOBAL_MEMORY) && ctx->allow_lds && ctx->lds_capable && ctx->ticket.p;
+    if (n_frames > 1 && ((flags & RT_RENDER_REFERENCE_ORDER) || use_wf || use_lds || (size_t)n_blocks * n_frames > 0x7FFFFFFFull)) {
+        // one frame per launch for these paths
+        for (int f = 0; f < n_frames; f++) {
+            const size_t off = (size_t)f * frame_stride;
+            const int rc = render_frames(ctx, camera + 14 * f, 1, 0, max_bounces, flags, band_rows, rank, world,
+                                         d_rgb ? d_rgb + 3 * off : nullptr, d_rgba8 ? d_rgba8 + 4 * off : nullptr,
+                                         d_primary_id ? d_primary_id + off : nullptr, d_final_id ? d_final_id + off : nullptr,
+                                         d_bounces ? d_bounces + off : nullptr, d_stats, stream);
+            if (rc != RT_OK) return rc;
+        }
+        return RT_OK;
+    }
     if (flags & RT_RENDER_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
     else if (use_wf)
         return launch_wavefront(ctx, a, st);
-    else if (use_bvh && !(flags & RT_RENDER_GLOBAL_MEMORY) && ctx->allow_lds && ctx->lds_capable && ctx->ticket.p) {
+    else if (use_lds) {
         // LDS-resident persistent kernel: one workgroup per CU; each of its waves draws one ticket
         // past the end, so the launch consumes exactly n_tickets + n_waves tickets
         const int per = a.supertile * a.supertile;
@@ -576,11 +601,44 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
         hipLaunchKernelGGL(k_render_bvh_lds, dim3(grid), dim3(LDS_BLOCK), ctx->lds_bytes, st, a);
         if ((rc = chain_end(ctx, st)) != RT_OK) return rc;
     } else if (use_bvh)
-        hipLaunchKernelGGL(ctx->info.unbounded_triangles > 0 ? k_render_bvh<true> : k_render_bvh<false>, dim3(n_blocks),
-                           dim3(64 * BLOCK_WAVES), (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4, st, a);
+        hipLaunchKernelGGL(ctx->info.unbounded_triangles > 0 ? k_render_bvh<true> : k_render_bvh<false>,
+                           dim3(n_blocks * n_frames), dim3(64 * BLOCK_WAVES),
+                           (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4, st, a);
     else
-        hipLaunchKernelGGL(k_render<false>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
+        hipLaunchKernelGGL(k_render<false>, dim3(n_blocks * n_frames), dim3(64 * BLOCK_WAVES), 0, st, a);
     HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int flags, int band_rows, int rank,
+                     int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id, int32_t* d_final_id,
+                     int32_t* d_bounces, rt_stats* d_stats, void* stream) {
+    return render_frames(ctx, camera, 1, 0, max_bounces, flags, band_rows, rank, world, d_rgb, d_rgba8, d_primary_id,
+                         d_final_id, d_bounces, d_stats, stream);
+}
+
+int rt_render_frames_device(rt_ctx* ctx, const float* cameras, int n_frames, int max_bounces, int flags, int band_rows,
+                            int rank, int world, int64_t frame_stride, float* d_rgb, uint8_t* d_rgba8,
+                            int32_t* d_primary_id, int32_t* d_final_id, int32_t* d_bounces, void* stream) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (!cameras || n_frames <= 0 || frame_stride < 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null cameras, no frames or a negative frame stride");
+    int w, h;
+    if (camera_size(cameras, &w, &h) != RT_OK)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "camera[12..13] must hold an integral width/height in 1..65536");
+    if (band_rows <= 0 || world <= 0 || rank < 0 || rank >= world)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad band_rows / rank / world");
+    if (n_frames > 1 && (uint64_t)frame_stride < (uint64_t)rt_local_rows(h, band_rows, rank, world) * (uint64_t)w)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "frame_stride is smaller than one frame's local pixels");
+    for (int f0 = 0; f0 < n_frames; f0 += MAX_BATCH) {  // MAX_BATCH frames per launch
+        const int n = std::min(MAX_BATCH, n_frames - f0);
+        const size_t off = (size_t)f0 * (size_t)frame_stride;
+        const int rc = render_frames(ctx, cameras + 14 * f0, n, (uint64_t)frame_stride, max_bounces, flags, band_rows, rank,
+                                     world, d_rgb ? d_rgb + 3 * off : nullptr, d_rgba8 ? d_rgba8 + 4 * off : nullptr,
+                                     d_primary_id ? d_primary_id + off : nullptr, d_final_id ? d_final_id + off : nullptr,
+                                     d_bounces ? d_bounces + off : nullptr, nullptr, stream);
+        if (rc != RT_OK) return rc;
+    }
     return RT_OK;
 }
 

@@ -87,19 +87,23 @@ class ShardedFrames:
         self.pending = None
 
     def render(self, cameras, max_bounces):
-        """Launch all frames' local bands; on return the current stream waits for them."""
+        """Launch all frames' local bands; on return the current stream waits for them.  The frames go to
+        the library in batches of 8 (one launch each for the megakernels, rt_render_frames_device), batches
+        alternating over the streams so that the tail of one launch overlaps the head of the next."""
         main = torch.cuda.current_stream()
         out = self.local if self.world > 1 else self.frames  # a single rank renders straight into the frames
-        if not self.streams:
-            self.rt.render_device(cameras[0], max_bounces, rgba8=out[0].data_ptr(), band_rows=self.band,
-                                  rank=self.rank, world=self.world, stream=main.cuda_stream)
+        stride = out.stride(0) // 4  # pixels between consecutive frames
+        batches = [(f0, min(f0 + 8, self.F)) for f0 in range(0, self.F, 8)]
+        if len(batches) == 1 or not self.streams:
+            self.rt.render_frames_device(cameras[:self.F], max_bounces, stride, rgba8=out.data_ptr(), band_rows=self.band,
+                                         rank=self.rank, world=self.world, stream=main.cuda_stream)
             return
         for s in self.streams:
             s.wait_stream(main)
-        for f, cam in enumerate(cameras):
-            s = self.streams[f % len(self.streams)]
-            self.rt.render_device(cam, max_bounces, rgba8=out[f].data_ptr(), band_rows=self.band, rank=self.rank,
-                                  world=self.world, stream=s.cuda_stream)
+        for k, (f0, f1) in enumerate(batches):
+            s = self.streams[k % len(self.streams)]
+            self.rt.render_frames_device(cameras[f0:f1], max_bounces, stride, rgba8=out[f0].data_ptr(),
+                                         band_rows=self.band, rank=self.rank, world=self.world, stream=s.cuda_stream)
         for s in self.streams:
             main.wait_stream(s)
 

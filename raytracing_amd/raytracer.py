@@ -159,6 +159,20 @@ class RayTracer:
                                                int(rank), int(world), vp(rgb), vp(rgba8), vp(primary_id),
                                                vp(final_id), vp(bounces), vp(stats), vp(stream)))
 
+    def render_frames_device(self, cameras, max_bounces, frame_stride, *, rgb=None, rgba8=None, primary_id=None,
+                             final_id=None, bounces=None, reference_order=False, band_rows=None, rank=0, world=1,
+                             stream=0):
+        """rt_render_frames_device: several frames of one size, frame f's planes f * frame_stride pixels after
+        frame 0's (device pointers); the megakernels take up to 8 frames per launch."""
+        cams = np.ascontiguousarray(cameras, dtype=np.float32).reshape(-1, 14)
+        if band_rows is None:
+            band_rows = int(cams[0, 13])
+        vp = lambda v: C.c_void_p(int(v)) if v else None  # noqa: E731
+        self._check(self._lib.rt_render_frames_device(self._ctx, N.ptr(cams), len(cams), int(max_bounces),
+                                                      1 if reference_order else 0, int(band_rows), int(rank),
+                                                      int(world), int(frame_stride), vp(rgb), vp(rgba8),
+                                                      vp(primary_id), vp(final_id), vp(bounces), vp(stream)))
+
     def unpermute_bands(self, gathered, out, elem_size, width, height, band_rows, world, stream=0):
         vp = lambda v: C.c_void_p(int(v)) if v else None  # noqa: E731
         self._check(self._lib.rt_unpermute_bands(self._ctx, vp(gathered), vp(out), int(elem_size), int(width),

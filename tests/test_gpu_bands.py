@@ -102,3 +102,36 @@ def test_nccl_world_size_one(rt, scene_of):
         assert np.array_equal(frame.cpu().numpy(), rt.RenderGL(10, want=("rgba8",))["rgba8"])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,rank", [(1, 0), (3, 1), (8, 7)])
+def test_batched_launch_equals_one_launch_per_frame(world, rank, rt, scene_of, traversal):
+    """rt_render_frames_device: 11 cameras (more than the 8 of one launch) into strided planes must give,
+    bit for bit, what 11 rt_render_device calls give -- for the megakernels (one launch per 8 frames) and
+    for the staged pipeline (one launch sequence per frame)."""
+    import torch
+    from raytracing_amd import host
+    sc = scene_of("TestScene1")
+    rt.SendPrimitivesToShader(sc)
+    w, h, band, depth, F = 200, 120, 8, 3, 11
+    cams = np.stack([host.camera_orbit(7 * f, 96, w, h) for f in range(F)])
+    rows = rt.local_rows(h, band, rank, world)
+    stride = rows * w + 64                     # padded plane stride
+    st = torch.cuda.current_stream().cuda_stream
+    planes = {k: torch.full((F, stride) + shp, 77, dtype=dt, device="cuda")
+              for k, shp, dt in (("rgba8", (4,), torch.uint8), ("rgb", (3,), torch.float32),
+                                 ("primary_id", (), torch.int32), ("final_id", (), torch.int32),
+                                 ("bounces", (), torch.int32))}
+    rt.render_frames_device(cams, depth, stride, band_rows=band, rank=rank, world=world, stream=st,
+                            **{k: v.data_ptr() for k, v in planes.items()})
+    torch.cuda.synchronize()
+    for f in range(F):
+        one = {k: torch.empty_like(v[0]) for k, v in planes.items()}
+        rt.render_device(cams[f], depth, band_rows=band, rank=rank, world=world, stream=st,
+                         **{k: v.data_ptr() for k, v in one.items()})
+        torch.cuda.synchronize()
+        for k in planes:
+            a, b = planes[k][f, :rows * w], one[k][:rows * w]
+            assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (k, f)
+            assert bool((planes[k][f, rows * w:] == 77).all()), "padding touched"
+    assert not torch.equal(planes["rgba8"][0], planes["rgba8"][5])
