@@ -342,8 +342,27 @@ def main():
                                 "ms_per_frame": round(ms, 4), "Mrays_per_s": round(total_rays(st) / ms / 1e3, 1),
                                 "rays": total_rays(st), "algorithmic_GBps": round(ab / ms / 1e6, 1),
                                 "scene_build_s": round(t_build, 2)}
-            result["extra"] = extras
             rt.SendPrimitivesToShader(sc)
+            # the headline workload as a throughput job: 8 orbit frames per launch (rt_render_frames_device).
+            # A single 1080p frame leaves ~0.1 ms of ramp and tail per launch on the table; `value` above is
+            # the single-frame figure (one step = one frame, as the reference draws them).
+            batch = np.stack(orbit_cameras(sc, W, H, 8))
+            out8 = torch.empty((8, H, W, 4), dtype=torch.uint8, device="cuda")
+            s = torch.cuda.current_stream()
+            for _ in range(3):
+                rt.render_frames_device(batch, depth, H * W, rgba8=out8.data_ptr(), stream=s.cuda_stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            for _ in range(10):
+                rt.render_frames_device(batch, depth, H * W, rgba8=out8.data_ptr(), stream=s.cuda_stream)
+            e1.record(s)
+            torch.cuda.synchronize()
+            ms8 = e0.elapsed_time(e1) / 10
+            rays8 = sum(total_rays(device_stats(rt, torch, c, depth)) for c in batch)
+            extras[args.workload + "_8_frames_per_launch"] = {
+                "ms_per_launch": round(ms8, 4), "ms_per_frame": round(ms8 / 8, 4),
+                "Mrays_per_s": round(rays8 / ms8 / 1e3, 1), "rays": rays8}
+            result["extra"] = extras
         if not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(sc, cams[0], depth, W, H)
             result["gpu_over_cpu_1thread"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
