@@ -51,6 +51,7 @@ struct DevScene {
     // tight per-primitive tree (rt_bvh.h build_tight), stored behind the image as further nodes of
     // `bvh`: its root holder is node tight_root (0 = not built / not used).  Only rays with
     // max_k(|o_k| + extent_k) <= tight_e may walk it; *_slot_leaf map a slot to its reference leaf record.
+    float root_lo[3], root_hi[3];  // the reference tree's root box (host side: tile priority)
     uint32_t tight_root;
     float tight_e;
     const int32_t* tri_slot_leaf;

@@ -483,6 +483,15 @@ __device__ __forceinline__ uint32_t quantise(float v) {
     return (uint32_t)rintf(v * 255.0f);
 }
 
+// Priority rectangle (super-tile coordinates, inclusive; x0 > x1 = none): its super-tiles are dealt out
+// first, the others after them in row-major order.  The longest waves of a frame are those that see the
+// mesh (bounce + shadow rays that traverse); started in the middle of the launch they end long after
+// everything else has drained (measured on the teapot frame: all waves started by 165 us, the last one
+// ended at 272 us; tools/diag_wave_times.py), started first they overlap the rest.  Pure scheduling: every
+// tile is still rendered exactly once.
+struct PriorityRect {
+    int x0, y0, x1, y1;
+};
 constexpr int MAX_BATCH = 8;  // frames one launch of the megakernels can render (rt_render_frames_device)
 struct RenderArgs {
     DevScene scene;
@@ -491,6 +500,7 @@ struct RenderArgs {
     int n_frames;                       // blocks [f * blocks_per_frame, (f+1) * blocks_per_frame) render frame f
     int blocks_per_frame;
     unsigned long long frame_stride;    // pixels between consecutive frames in every output plane
+    PriorityRect prio[MAX_BATCH];       // per frame: super-tiles dealt out first (block_to_tile)
     int max_bounces;
     int width, height;   // full frame
     int local_rows;      // rows this launch renders
@@ -511,7 +521,7 @@ struct RenderArgs {
 // the camera is picked with compile-time indices only (a dynamic index into the by-value argument struct
 // would send the whole struct to scratch memory).  Returns the frame; *block becomes the block index
 // inside the frame.
-__device__ __forceinline__ int select_frame(const RenderArgs& a, int* block, float cam[14]) {
+__device__ __forceinline__ int select_frame(const RenderArgs& a, int* block, float cam[14], PriorityRect* prio) {
     int f = 0;
     if (a.n_frames > 1) {
         f = *block / a.blocks_per_frame;
@@ -524,6 +534,13 @@ __device__ __forceinline__ int select_frame(const RenderArgs& a, int* block, flo
         for (int q = 1; q < MAX_BATCH; q++) v = (f == q) ? a.more_cams[q - 1][k] : v;
         cam[k] = v;
     }
+    PriorityRect pr = a.prio[0];
+#pragma unroll
+    for (int q = 1; q < MAX_BATCH; q++) {
+        pr.x0 = (f == q) ? a.prio[q].x0 : pr.x0, pr.y0 = (f == q) ? a.prio[q].y0 : pr.y0;
+        pr.x1 = (f == q) ? a.prio[q].x1 : pr.x1, pr.y1 = (f == q) ? a.prio[q].y1 : pr.y1;
+    }
+    *prio = pr;
     return f;
 }
 
@@ -547,13 +564,38 @@ __device__ __forceinline__ int global_row(const RenderArgs& a, int r) {
 // every slot gets super-tiles from all over the image (so sky, floor and mesh work is balanced
 // across XCDs -- one contiguous run of tiles per XCD left the sky XCDs idle: 30 % wave-slot use).
 // Returns false for the padding blocks of a partial super-tile.
-__device__ __forceinline__ bool block_to_tile(int b, int st, int tiles_x, int tiles_y, int* tx, int* ty) {
+__device__ __forceinline__ void priority_super(int k, int sx_n, PriorityRect pr, int* sx, int* sy) {
+    const int rw = pr.x1 - pr.x0 + 1, rh = pr.y1 - pr.y0 + 1;
+    if (rw <= 0 || rh <= 0) {
+        *sx = k % sx_n, *sy = k / sx_n;
+        return;
+    }
+    const int n_rect = rw * rh;
+    if (k < n_rect) {
+        *sx = pr.x0 + k % rw, *sy = pr.y0 + k / rw;
+        return;
+    }
+    k -= n_rect;
+    const int below = pr.y0 * sx_n, side = sx_n - rw, mid = rh * side;
+    if (k < below) {
+        *sx = k % sx_n, *sy = k / sx_n;
+    } else if (k - below < mid) {  // side > 0 here
+        k -= below;
+        const int c = k % side;
+        *sx = c < pr.x0 ? c : c + rw, *sy = pr.y0 + k / side;
+    } else {
+        k -= below + mid;
+        *sx = k % sx_n, *sy = pr.y1 + 1 + k / sx_n;
+    }
+}
+__device__ __forceinline__ bool block_to_tile(int b, int st, int tiles_x, int tiles_y, PriorityRect pr, int* tx, int* ty) {
     const int x = b & 7, j = b >> 3;
     const int per = st * st;
     const int super = (j / per) * 8 + x;
     const int in = j % per;
     const int sx_n = (tiles_x + st - 1) / st;
-    const int sx = super % sx_n, sy = super / sx_n;
+    int sx, sy;
+    priority_super(super, sx_n, pr, &sx, &sy);
     *tx = sx * st + in % st;
     *ty = sy * st + in / st;
     return *tx < tiles_x && *ty < tiles_y;
@@ -575,8 +617,9 @@ template <bool REF>
 __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a) {
     int tx, ty, block = blockIdx.x;
     float cam[14];
-    const int frame = select_frame(a, &block, cam);
-    const bool in_image = block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
+    PriorityRect prio;
+    const int frame = select_frame(a, &block, cam, &prio);
+    const bool in_image = block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, prio, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
     const int r = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);  // local row
@@ -621,8 +664,9 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) __attribute__((amdgpu_waves_per_e
     const RenderArgs a) {
     int tx, ty, block = blockIdx.x;
     float cam[14];
-    const int frame = select_frame(a, &block, cam);
-    const bool in_image = block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, &tx, &ty);
+    PriorityRect prio;
+    const int frame = select_frame(a, &block, cam, &prio);
+    const bool in_image = block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, prio, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
     const int r = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);
@@ -634,10 +678,20 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) __attribute__((amdgpu_waves_per_e
 #else
     const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.bvh_levels + lane};
 #endif
+#ifdef RT_DIAG_WAVE_TIMES  // diagnostic build only: id planes receive each wave's start / end on the 100 MHz clock
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (live) {
         const PixelOut p =
             shade_pixel<false>(a.scene, g, cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, nullptr);
         store_pixel(a, frame, x, r, p);
+#ifdef RT_DIAG_WAVE_TIMES
+        {
+            const size_t i = (size_t)frame * a.frame_stride + (size_t)r * a.width + x;
+            if (a.primary_id) a.primary_id[i] = (int32_t)(uint32_t)diag_t0;
+            if (a.final_id) a.final_id[i] = (int32_t)(uint32_t)__builtin_amdgcn_s_memrealtime();
+        }
+#endif
 #ifdef RT_DIAG_STEPS  // planes receive: bounces <- node steps, final_id <- primitive tests, primary_id <- wave
                       // iterations (node << 16 | leaf) credited to the first active lane, rgb.x <- unused
         const size_t i = (size_t)r * a.width + x;

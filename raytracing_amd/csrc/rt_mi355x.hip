@@ -36,6 +36,7 @@ struct rt_ctx {
     // scene buffers
     DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights;
     DevBuf tri_slot_leaf, sphere_slot_leaf;  // tight tree only (rt_bvh.h)
+    bool prioritise = true;   // RT_PRIORITISE=0 (development): deal the tiles out in plain row-major order
     bool build_tight = true;  // RT_OPTION_TIGHT_TREE (takes effect at the next upload and at once for renders)
     int traversal = RT_TRAVERSAL_AUTO;  // RT_OPTION_TRAVERSAL
     int bvh_min_nodes = 0;              // auto: scenes with at least this many flat nodes take the BVH kernel
@@ -240,6 +241,7 @@ int rt_create(int device_id, rt_ctx** out) {
         const int t = atoi(v);
         if (t >= 1 && t <= 64) ctx->wf_waves_per_cu = t;
     }
+    if (const char* v = getenv("RT_PRIORITISE")) ctx->prioritise = atoi(v) != 0;
     if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development overrides
     if (const char* v = getenv("RT_WF_MIN_NODES")) ctx->wf_min_nodes = std::max(0, atoi(v));
     if (const char* v = getenv("RT_TRAVERSAL")) {  // development override of RT_OPTION_TRAVERSAL
@@ -406,6 +408,12 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     s.bvh = bvh.nodes.empty() ? nullptr : (const float4*)ctx->geom.p + bvh_off;
     s.bvh_levels = std::max(bvh.levels, tight.nodes.empty() ? 0 : tight.levels);
     s.bvh_off = (int32_t)bvh_off;
+    for (int k = 0; k < 3; k++) s.root_lo[k] = s.root_hi[k] = 0.0f;
+    if (!flat.nodes.empty()) {
+        const rtf::FlatNode& root = flat.nodes[0];
+        s.root_lo[0] = root.minx, s.root_lo[1] = root.miny, s.root_lo[2] = root.minz;
+        s.root_hi[0] = root.maxx, s.root_hi[1] = root.maxy, s.root_hi[2] = root.maxz;
+    }
     s.tight_root = tight.nodes.empty() ? 0u : (uint32_t)bvh.nodes.size();
     s.tight_e = tight_e;
     s.tri_slot_leaf = (const int32_t*)ctx->tri_slot_leaf.p;
@@ -516,6 +524,46 @@ int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out) {
     return RT_OK;
 }
 
+// Screen columns (in super-tiles) that the scene's root box projects to: the tiles the kernels deal out
+// first (PriorityRect, rt_kernels.h).  The camera array holds the eye and three corners of the image
+// plane; a point P is seen at (u, v) with eye + s (P - eye) on the plane, i.e.
+// u e1 + v e2 - w (P - eye) = eye - BL with w = 1/s.  Any corner behind the eye, a degenerate camera or a
+// box wider than 60 % of the frame give "no priority".  Scheduling only: a wrong answer costs time, never
+// pixels.
+static PriorityRect priority_rect(const DevScene& sc, const float* cam, int width, int local_rows, int super_px) {
+    PriorityRect none{1, 1, 0, 0};
+    if (sc.n_nodes <= 0) return none;
+    const double eye[3] = {cam[0], cam[1], cam[2]};
+    double e1[3], e2[3], c[3];
+    for (int k = 0; k < 3; k++) e1[k] = (double)cam[6 + k] - cam[3 + k], e2[k] = (double)cam[9 + k] - cam[3 + k], c[k] = eye[k] - cam[3 + k];
+    double umin = 1e300, umax = -1e300;
+    for (int corner = 0; corner < 8; corner++) {
+        double q[3];
+        for (int k = 0; k < 3; k++) q[k] = ((corner >> k) & 1 ? sc.root_hi[k] : sc.root_lo[k]) - eye[k];
+        // Cramer: columns e1, e2, -q; right-hand side c
+        auto det = [](const double* a, const double* b, const double* d) {
+            return a[0] * (b[1] * d[2] - b[2] * d[1]) - b[0] * (a[1] * d[2] - a[2] * d[1]) + d[0] * (a[1] * b[2] - a[2] * b[1]);
+        };
+        const double nq[3] = {-q[0], -q[1], -q[2]};
+        const double D = det(e1, e2, nq);
+        if (!(std::fabs(D) > 1e-300)) return none;
+        const double u = det(c, e2, nq) / D, v = det(e1, c, nq) / D, w = det(e1, e2, c) / D;
+        if (!(w > 1e-9) || !(u == u) || !(v == v)) return none;  // behind the eye or at it
+        umin = std::min(umin, u), umax = std::max(umax, u);
+    }
+    const double x0 = std::max(0.0, umin * width), x1 = std::min((double)width - 1, umax * width);
+    if (!(x0 <= x1)) return none;  // off screen
+    if ((x1 - x0 + 1) > 0.6 * width) return none;  // most of the frame: nothing to prioritise
+    // The whole column range, not just the box's rows: the other long waves of a frame (the mesh's mirror
+    // image in a floor, the floor points whose shadow rays cross it) sit above and below it on the screen.
+    // Measured on the teapot frame: box rectangle 0.264 ms, full-height strip 0.244 ms, full-width strip
+    // 0.275 ms (= no priority).
+    PriorityRect pr;
+    pr.x0 = (int)x0 / super_px, pr.x1 = (int)x1 / super_px;
+    pr.y0 = 0, pr.y1 = std::max(local_rows - 1, 0) / super_px;
+    return pr;
+}
+
 // Core of rt_render_device / rt_render_frames_device: n_frames (<= MAX_BATCH) cameras of one size in one
 // launch of a megakernel; the staged pipeline, the LDS kernel and the reference-order kernel take one
 // frame per launch (callers loop).
@@ -554,6 +602,10 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
     const int n_super = ((a.tiles_x + a.supertile - 1) / a.supertile) * ((a.tiles_y + a.supertile - 1) / a.supertile);
     const int n_blocks = ((n_super + 7) / 8) * 8 * a.supertile * a.supertile;
     a.blocks_per_frame = n_blocks;
+    for (int f = 0; f < MAX_BATCH; f++) a.prio[f] = PriorityRect{1, 1, 0, 0};
+    if (ctx->prioritise)
+        for (int f = 0; f < n_frames; f++)
+            a.prio[f] = priority_rect(a.scene, camera + 14 * f, w, a.local_rows, a.supertile * TILE_X);
     a.rgb = d_rgb;
     a.rgba8 = (uint32_t*)d_rgba8;
     a.primary_id = d_primary_id;
