@@ -69,16 +69,22 @@ __device__ __forceinline__ uint32_t wf_active_count(const WfArgs& a) { return a.
 #ifndef RT_WF_VOTE
 #define RT_WF_VOTE 3  // a node step needs this many times as many lanes as stand at a leaf (wf_run)
 #endif
+#ifndef RT_WF_CHUNK
+#define RT_WF_CHUNK 512  // items per run a wave reserves at once (0: every refill draws from the global head).
+                         // Soup100k 1080p 14.4 -> 11.4 ms, Soup1M 4K 59.5 -> 57.5 ms with 24-lane refills
+#endif
 #ifndef RT_WF_NODE_REPS
 #define RT_WF_NODE_REPS 4  // node steps per won vote (wf_run): on the tight tree node steps outnumber primitive tests
                            // 25:1, so re-voting after every step is mostly overhead (the loop's scalar side: ballots,
                            // counts, branches).  Soup1M 4K: 1 -> 68.4 ms, 2 -> 63.4, 4 -> 59.5, 8 -> 60.1
 #endif
 #ifndef RT_WF_REFILL
-#define RT_WF_REFILL 40
+#define RT_WF_REFILL 24
 #endif
-constexpr int WF_REFILL = RT_WF_REFILL;  // idle lanes that trigger a refill.  Rays drawn together are neighbours (same light), so a larger
-// draw walks more coherently: with the tight tree 16 -> 95 ms, 24 -> 83, 32 -> 81, 40 -> 78, 48 -> 83 on Soup1M 4K
+constexpr int WF_REFILL = RT_WF_REFILL;  // idle lanes that trigger a refill.  Rays that run side by side should be neighbours
+// (same light, nearby origins): when every refill drew from the global head, larger draws walked more coherently
+// (16 -> 95 ms, 24 -> 83, 40 -> 78, 48 -> 83 on Soup1M 4K); with wave-owned runs (RT_WF_CHUNK) neighbours come
+// by construction and smaller refills keep more lanes busy (512-item runs: 16 -> 58.2 ms, 24 -> 57.5, 40 -> 60.7)
 
 // Draw work items for the idle lanes of the wave: one atomic per call.  Returns this lane's item or
 // 0xFFFFFFFF; *exhausted becomes true (wave-uniform) once the list has been handed out completely.
@@ -118,11 +124,35 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
     bool exhausted = false;
     uint32_t cur = NONE;
     int sp = 0, lk = 0;
+#if RT_WF_CHUNK
+    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the run of items this wave is handing out
+    uint32_t chunk = (total / (gridDim.x * 4u) + 63u) & ~63u;  // short lists: at least ~4 runs per wave
+    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)RT_WF_CHUNK ? (uint32_t)RT_WF_CHUNK : chunk);
+#endif
     for (;;) {
         const unsigned long long idle_m = __ballot(cur == NONE);
         const int n_idle = __popcll(idle_m);
         if (!exhausted && n_idle >= WF_REFILL) {
+#if RT_WF_CHUNK
+            // the wave owns a run of consecutive items (one atomic per run) and hands them to its idle lanes a
+            // few at a time: every lane of the wave then works on neighbouring rays, however small the refill
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if ((int)__lane_id() == 0) base = atomicAdd(head, chunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                chunk_next = base, chunk_end = base + chunk < total ? base + chunk : total;
+                if (base >= total) {
+                    exhausted = true;
+                    continue;
+                }
+            }
+            const uint32_t left = chunk_end - chunk_next, take = (uint32_t)n_idle < left ? (uint32_t)n_idle : left;
+            const uint32_t rank = (uint32_t)__popcll(idle_m & ((1ull << (int)__lane_id()) - 1ull));
+            const uint32_t k = (cur == NONE && rank < take) ? chunk_next + rank : NONE;
+            chunk_next += take;
+#else
             const uint32_t k = wf_draw(head, total, cur == NONE, &exhausted);
+#endif
             if (k != NONE && job.setup(k)) cur = job.tight ? job.a.scene.tight_root : 0u, sp = 0, lk = 0;  // a root holder
             continue;
         }
