@@ -336,7 +336,7 @@ def main():
                 cam = s2.camera_for(w, h)
                 st = device_stats(rt, torch, cam, d)
                 big = name.startswith("soup")
-                ms = time_single(rt, torch, cam, d, w, h, 3 if big else 20, 1 if big else 3)
+                ms = time_single(rt, torch, cam, d, w, h, 3 if big else 20, 2 if big else 3)  # >= 2 warm-up frames: AUTO times both kernels
                 ab = algorithmic_bytes(st, w, h)
                 extras[name] = {"traversal": KERNEL_OF.get(rt.scene_info()["traversal"], "?").split(" ")[0],
                                 "ms_per_frame": round(ms, 4), "Mrays_per_s": round(total_rays(st) / ms / 1e3, 1),

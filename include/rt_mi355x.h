@@ -82,8 +82,12 @@ enum {
     RT_OPTION_TIGHT_TREE = 4, /* 1 (default): uploads of large scenes also build a per-primitive tree that the
                                 staged pipeline walks as a filter in front of the reference's leaf-box rule
                                 (64 B per primitive, ~0.25 s of host time per million); 0: neither built nor used */
-    RT_OPTION_WAVEFRONT_MIN_NODES = 5 /* "large scene" threshold in flattened node records (default 30000):
-                                from it on AUTO picks RT_TRAVERSAL_WAVEFRONT and uploads build the tight tree */
+    RT_OPTION_WAVEFRONT_MIN_NODES = 5 /* scenes with at least this many flattened node records (default 1000) get the
+                                tight tree at upload and are candidates for RT_TRAVERSAL_WAVEFRONT under AUTO: the
+                                first render of a (scene, frame size, bounces) is timed with the megakernel, the
+                                second with the staged pipeline, later ones use the faster (size alone does not
+                                tell a triangle soup from a field of meshes); from 100000 nodes on AUTO takes the
+                                staged pipeline without asking */
 };
 enum {
     RT_TRAVERSAL_AUTO = 0,

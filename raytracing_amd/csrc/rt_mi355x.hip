@@ -36,6 +36,16 @@ struct rt_ctx {
     // scene buffers
     DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights;
     DevBuf tri_slot_leaf, sphere_slot_leaf;  // tight tree only (rt_bvh.h)
+    // AUTO between the megakernel and the staged pipeline for mid-sized scenes is decided by measurement
+    // (tune_begin): scene size does not tell a triangle soup, where the staged pipeline is 1.8x faster at
+    // 5.7 k nodes, from a field of meshes, where it is 3x slower at 18 k
+    struct Tune {
+        long long key = -1;            // (upload, frame size, bounces) the measurements belong to
+        float ms[2] = {-1.0f, -1.0f};  // measured GPU time of [0] megakernel, [1] staged pipeline
+        hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        bool pending[2] = {false, false};
+    } tune;
+    long long scene_serial = 0;
     bool prioritise = true;   // RT_PRIORITISE=0 (development): deal the tiles out in plain row-major order
     bool build_tight = true;  // RT_OPTION_TIGHT_TREE (takes effect at the next upload and at once for renders)
     int traversal = RT_TRAVERSAL_AUTO;  // RT_OPTION_TRAVERSAL
@@ -51,8 +61,9 @@ struct rt_ctx {
     bool allow_lds = false;     // RT_OPTION_USE_LDS: opt-in, measured slower than the L2-resident walk
     // path state of the wavefront pipeline (rt_wavefront.h; grow only)
     DevBuf wf_org, wf_dir, wf_mult, wf_final, wf_list0, wf_list1, wf_blocked, wf_counters;
-    int wf_min_nodes = 8000;   // auto: scenes with at least this many flat nodes take the wavefront pipeline
-                               // (Soup at 1080p with the tight tree: 5.7 k nodes 9.7 vs 10.1 ms for the megakernel, 2.9 k nodes 8.9 vs 6.4)
+    int wf_min_nodes = 1000;   // scenes with at least this many flat nodes get the tight tree and are candidates for
+                               // the staged pipeline under AUTO (decided by measurement, tune_begin)
+    int wf_sure_nodes = 100000;  // ... and from here on they take it without asking
     int wf_max_bounces = 64;   // beyond this the per-bounce launches stop paying: megakernel instead
     int wf_waves_per_cu = 24;  // persistent waves of the two trace stages
     // The wavefront path state and the LDS kernel's ticket counter are per context: renders that use
@@ -115,7 +126,7 @@ int pick_traversal(const rt_ctx* ctx, const DevScene& sc, int max_bounces) {
     const bool wf_ok = max_bounces <= ctx->wf_max_bounces;
     if (ctx->traversal == RT_TRAVERSAL_WAVEFRONT) return wf_ok ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
     if (ctx->traversal == RT_TRAVERSAL_BVH) return RT_TRAVERSAL_BVH;
-    if (wf_ok && sc.n_nodes >= ctx->wf_min_nodes) return RT_TRAVERSAL_WAVEFRONT;
+    if (wf_ok && sc.n_nodes >= std::max(ctx->wf_sure_nodes, ctx->wf_min_nodes)) return RT_TRAVERSAL_WAVEFRONT;  // between: tune_begin
     return sc.n_nodes >= ctx->bvh_min_nodes ? RT_TRAVERSAL_BVH : RT_TRAVERSAL_WAVE;
 }
 
@@ -266,6 +277,9 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->chain_done) (void)hipEventDestroy(ctx->chain_done);
+    for (auto& pair : ctx->tune.ev)
+        for (hipEvent_t e : pair)
+            if (e) (void)hipEventDestroy(e);
     DevBuf* wf[] = {&ctx->wf_org,   &ctx->wf_dir,   &ctx->wf_mult,    &ctx->wf_final,
                     &ctx->wf_list0, &ctx->wf_list1, &ctx->wf_blocked, &ctx->wf_counters};
     for (DevBuf* b : wf) release(*b);
@@ -440,6 +454,7 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     inf.device_bytes += (int64_t)(tight.nodes.size() * sizeof(rtb::Node) + (tri_slot_leaf.size() + sphere_slot_leaf.size()) * 4);
     ctx->lds_capable = !bvh.nodes.empty() && ctx->lds_bytes <= (size_t)ctx->lds_limit;
     ctx->has_scene = true;
+    ctx->scene_serial++;
     return RT_OK;
 }
 
@@ -521,6 +536,11 @@ int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out) {
     if (!ctx->has_scene) return RT_ERR_NO_SCENE;
     *out = ctx->info;
     out->traversal = pick_traversal(ctx, ctx->scene, 10);
+    // a mid-sized scene under AUTO: the measured verdict once there is one (tune_begin)
+    const rt_ctx::Tune& t = ctx->tune;
+    if (ctx->traversal == RT_TRAVERSAL_AUTO && out->traversal == RT_TRAVERSAL_BVH && (t.key >> 40) == ctx->scene_serial &&
+        t.ms[0] >= 0 && t.ms[1] >= 0 && ctx->scene.n_nodes >= ctx->wf_min_nodes)
+        out->traversal = t.ms[1] < t.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
     return RT_OK;
 }
 
@@ -564,13 +584,54 @@ static PriorityRect priority_rect(const DevScene& sc, const float* cam, int widt
     return pr;
 }
 
+// AUTO for mid-sized scenes: the first render of a (scene, frame size, bounces) runs the megakernel between
+// two events, the next one the staged pipeline, and from then on the faster of the two is used (results
+// are identical either way).  Nothing waits: a measurement is read when its events have completed, until
+// then renders keep the megakernel.  Returns the traversal to force (RT_TRAVERSAL_BVH / WAVEFRONT) or 0 for
+// "no opinion"; *timed = slot whose stop event tune_end must record, or -1.
+static int tune_begin(rt_ctx* ctx, int w, int local_rows, int max_bounces, hipStream_t st, int* timed) {
+    *timed = -1;
+    const DevScene& sc = ctx->scene;
+    if (!ctx->has_scene || ctx->traversal != RT_TRAVERSAL_AUTO || sc.bvh == nullptr || sc.bvh_levels > rtb::MAX_LEVELS ||
+        max_bounces > ctx->wf_max_bounces || sc.n_nodes < ctx->wf_min_nodes || sc.n_nodes >= ctx->wf_sure_nodes)
+        return 0;
+    rt_ctx::Tune& t = ctx->tune;
+    const long long key = (ctx->scene_serial << 40) ^ ((long long)w << 24) ^ ((long long)local_rows << 8) ^ max_bounces;
+    if (t.key != key) {
+        t.key = key;
+        t.ms[0] = t.ms[1] = -1.0f;
+        t.pending[0] = t.pending[1] = false;
+    }
+    for (int k = 0; k < 2; k++)
+        if (t.pending[k] && hipEventQuery(t.ev[k][1]) == hipSuccess) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, t.ev[k][0], t.ev[k][1]) == hipSuccess) t.ms[k] = ms;
+            t.pending[k] = false;
+        }
+    (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error
+    for (int k = 0; k < 2; k++)
+        if (t.ms[k] < 0 && !t.pending[k]) {
+            for (int e = 0; e < 2; e++)
+                if (!t.ev[k][e] && hipEventCreate(&t.ev[k][e]) != hipSuccess) return 0;
+            if (hipEventRecord(t.ev[k][0], st) != hipSuccess) return 0;
+            *timed = k;
+            return k == 0 ? RT_TRAVERSAL_BVH : RT_TRAVERSAL_WAVEFRONT;
+        }
+    if (t.ms[0] >= 0 && t.ms[1] >= 0) return t.ms[1] < t.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
+    return RT_TRAVERSAL_BVH;
+}
+static void tune_end(rt_ctx* ctx, int timed, hipStream_t st) {
+    if (timed < 0) return;
+    if (hipEventRecord(ctx->tune.ev[timed][1], st) == hipSuccess) ctx->tune.pending[timed] = true;
+}
+
 // Core of rt_render_device / rt_render_frames_device: n_frames (<= MAX_BATCH) cameras of one size in one
 // launch of a megakernel; the staged pipeline, the LDS kernel and the reference-order kernel take one
 // frame per launch (callers loop).
 static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_t frame_stride, int max_bounces,
                          int flags, int band_rows, int rank, int world, float* d_rgb, uint8_t* d_rgba8,
                          int32_t* d_primary_id, int32_t* d_final_id, int32_t* d_bounces, rt_stats* d_stats,
-                         void* stream) {
+                         void* stream, int force_trav = 0) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_upload_scene has not succeeded on this context");
     int w, h;
@@ -616,7 +677,7 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
     a.ticket_base = 0;
     if (a.tiles_y == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
-    int trav = pick_traversal(ctx, a.scene, max_bounces);
+    int trav = force_trav ? force_trav : pick_traversal(ctx, a.scene, max_bounces);
     // the staged pipeline indexes (pixel, light) work items with 32 bits: beyond that, the megakernel
     if (trav == RT_TRAVERSAL_WAVEFRONT &&
         (size_t)((w + 7) / 8) * ((a.local_rows + 7) / 8) * 64 * (size_t)std::max(a.scene.lights_len / 6, 1) >= 0xFFFFFFF0ull)
@@ -630,7 +691,7 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
             const int rc = render_frames(ctx, camera + 14 * f, 1, 0, max_bounces, flags, band_rows, rank, world,
                                          d_rgb ? d_rgb + 3 * off : nullptr, d_rgba8 ? d_rgba8 + 4 * off : nullptr,
                                          d_primary_id ? d_primary_id + off : nullptr, d_final_id ? d_final_id + off : nullptr,
-                                         d_bounces ? d_bounces + off : nullptr, d_stats, stream);
+                                         d_bounces ? d_bounces + off : nullptr, d_stats, stream, force_trav);
             if (rc != RT_OK) return rc;
         }
         return RT_OK;
@@ -665,8 +726,14 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
 int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int flags, int band_rows, int rank,
                      int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id, int32_t* d_final_id,
                      int32_t* d_bounces, rt_stats* d_stats, void* stream) {
-    return render_frames(ctx, camera, 1, 0, max_bounces, flags, band_rows, rank, world, d_rgb, d_rgba8, d_primary_id,
-                         d_final_id, d_bounces, d_stats, stream);
+    int timed = -1, force = 0, w, h;
+    if (ctx && ctx->has_scene && !(flags & RT_RENDER_REFERENCE_ORDER) && camera_size(camera, &w, &h) == RT_OK &&
+        band_rows > 0 && world > 0 && rank >= 0 && rank < world && hipSetDevice(ctx->device) == hipSuccess)
+        force = tune_begin(ctx, w, rt_local_rows(h, band_rows, rank, world), max_bounces, (hipStream_t)stream, &timed);
+    const int rc = render_frames(ctx, camera, 1, 0, max_bounces, flags, band_rows, rank, world, d_rgb, d_rgba8,
+                                 d_primary_id, d_final_id, d_bounces, d_stats, stream, force);
+    tune_end(ctx, timed, (hipStream_t)stream);
+    return rc;
 }
 
 int rt_render_frames_device(rt_ctx* ctx, const float* cameras, int n_frames, int max_bounces, int flags, int band_rows,
@@ -682,15 +749,23 @@ int rt_render_frames_device(rt_ctx* ctx, const float* cameras, int n_frames, int
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "bad band_rows / rank / world");
     if (n_frames > 1 && (uint64_t)frame_stride < (uint64_t)rt_local_rows(h, band_rows, rank, world) * (uint64_t)w)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "frame_stride is smaller than one frame's local pixels");
+    int timed = -1, force = 0;
+    if (ctx->has_scene && !(flags & RT_RENDER_REFERENCE_ORDER) && n_frames == 1 && hipSetDevice(ctx->device) == hipSuccess)
+        force = tune_begin(ctx, w, rt_local_rows(h, band_rows, rank, world), max_bounces, (hipStream_t)stream, &timed);
+    else if (ctx->has_scene && ctx->tune.ms[0] >= 0 && ctx->tune.ms[1] >= 0 && !(flags & RT_RENDER_REFERENCE_ORDER) &&
+             ctx->traversal == RT_TRAVERSAL_AUTO && ctx->scene.n_nodes >= ctx->wf_min_nodes && ctx->scene.n_nodes < ctx->wf_sure_nodes &&
+             (ctx->tune.key >> 40) == ctx->scene_serial && max_bounces <= ctx->wf_max_bounces)
+        force = ctx->tune.ms[1] < ctx->tune.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;  // batches reuse a verdict
     for (int f0 = 0; f0 < n_frames; f0 += MAX_BATCH) {  // MAX_BATCH frames per launch
         const int n = std::min(MAX_BATCH, n_frames - f0);
         const size_t off = (size_t)f0 * (size_t)frame_stride;
         const int rc = render_frames(ctx, cameras + 14 * f0, n, (uint64_t)frame_stride, max_bounces, flags, band_rows, rank,
                                      world, d_rgb ? d_rgb + 3 * off : nullptr, d_rgba8 ? d_rgba8 + 4 * off : nullptr,
                                      d_primary_id ? d_primary_id + off : nullptr, d_final_id ? d_final_id + off : nullptr,
-                                     d_bounces ? d_bounces + off : nullptr, nullptr, stream);
+                                     d_bounces ? d_bounces + off : nullptr, nullptr, stream, force);
         if (rc != RT_OK) return rc;
     }
+    tune_end(ctx, timed, (hipStream_t)stream);
     return RT_OK;
 }
 

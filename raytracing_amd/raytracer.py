@@ -37,7 +37,7 @@ def check_accel(accel, n_spheres, n_triangles):
     return {n: int(getattr(info, n)) for n, _ in N.rt_scene_info._fields_ if n != "reserved"}
 
 
-def check_scene(scene, tight_min_nodes=8000):
+def check_scene(scene, tight_min_nodes=1000):
     """rt_check_scene: the host half of rt_upload_scene (validation, cull preconditions, both trees) plus a
     structural self-check of the trees.  Returns the scene info or raises RtError (no GPU needed)."""
     lib = N.device_lib()

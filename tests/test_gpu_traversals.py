@@ -330,3 +330,39 @@ def test_untraced_shadow_rays_leave_every_float_as_it_was(mode, label, rt_mode, 
     assert np.array_equal(fast["primary_id"], slow["primary_id"]) and np.array_equal(fast["final_id"], slow["final_id"])
     assert np.array_equal(fast["rgb"].view(np.uint32), slow["rgb"].view(np.uint32))
     assert_frame_matches(fast, oracle_render(odd, cam, 4, threads=16), "odd materials " + label)
+
+
+def test_auto_times_both_kernels_on_mid_sized_scenes(rt_mode, scene_of):
+    """Between 1000 and 100000 flattened nodes AUTO renders the first frame with the megakernel, the second
+    with the staged pipeline (both between events) and then keeps the faster: a triangle soup of 10 k
+    triangles ends up on the staged pipeline, a field of teapots with three times as many nodes on the
+    megakernel.  Every frame on the way is the same frame."""
+    import torch
+    rt = rt_mode
+    sc_soup = scene_of("Soup", [10000, 100, 8])
+    base = scene_of("TeapotScene")
+    tris = []
+    for k in range(12):
+        t = base.trianglesData.copy()
+        for f in ("PointA", "PointB", "PointC"):
+            t[f] += np.array([(k % 6 - 2.5) * 3.0, 0.0, (k // 6) * 3.5 - 2.0], np.float32)
+        tris.append(t)
+    from raytracing_amd import host
+    tri = np.concatenate(tris)
+    field = Scene(base.spheresData, base.planesData, tri, host.accel_from_structs(base.spheresData, tri),
+                  base.lightsData, base.cameraData)
+    st = torch.cuda.current_stream().cuda_stream
+    for sc, expect in ((sc_soup, rt.TRAVERSAL_WAVEFRONT), (field, rt.TRAVERSAL_BVH)):
+        _set_mode(rt, 0)
+        rt.set_option(rt.OPTION_WAVEFRONT_MIN_NODES, 1000)
+        rt.SendPrimitivesToShader(sc)
+        assert 1000 <= rt.scene_info()["n_nodes"] < 100000 and rt.scene_info()["tight_nodes"] > 0
+        cam = sc.camera_for(640, 360)
+        frames = []
+        for _ in range(4):
+            out = torch.empty((360, 640, 4), dtype=torch.uint8, device="cuda")
+            rt.render_device(cam, 4, rgba8=out.data_ptr(), stream=st)
+            torch.cuda.synchronize()
+            frames.append(out)
+        assert all(torch.equal(frames[0], f) for f in frames[1:])
+        assert rt.scene_info()["traversal"] == expect

@@ -23,7 +23,7 @@ def test_reference_scenes_pass_every_precondition(name, params, scene_of):
     assert 0 < info["tight_levels"] <= 32 and 0 < info["bvh_levels"] <= 32
     assert info["unbounded_triangles"] == (19 if name == "TeapotTable" else 0)
     small = check_scene(sc)                             # default threshold: only large scenes get it
-    assert (small["tight_nodes"] > 0) == (small["n_nodes"] >= 8000)
+    assert (small["tight_nodes"] > 0) == (small["n_nodes"] >= 1000)
 
 
 def test_builder_output_does_not_depend_on_threads(scene_of):

@@ -28,7 +28,7 @@ for name in names:
                          bounces=bnc.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         big = name.startswith("soup")
-        ms = B.time_single(rt, torch, cam, d, w, h, 3 if big else 30, 1 if big else 5)
+        ms = B.time_single(rt, torch, cam, d, w, h, 3 if big else 30, 2 if big else 5)
         res[label] = (pid, fid, bnc, rgba, ms)
     if os.environ.get("AB_REF"):
         pid = torch.empty((h, w), dtype=torch.int32, device="cuda"); fid = torch.empty_like(pid); bnc = torch.empty_like(pid)

@@ -13,5 +13,5 @@ for name in names:
     cam = sc.camera_for(w, h)
     st = B.device_stats(rt, torch, cam, d)
     big = name.startswith("soup")
-    ms = B.time_single(rt, torch, cam, d, w, h, 3 if big else 30, 1 if big else 5)
+    ms = B.time_single(rt, torch, cam, d, w, h, 3 if big else 30, 2 if big else 5)
     print(f"{name:24s} {ms:9.4f} ms  {B.total_rays(st)/ms/1e3:10.1f} Mrays/s  alg {B.algorithmic_bytes(st,w,h)/ms/1e6:9.1f} GB/s", flush=True)
