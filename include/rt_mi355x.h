@@ -77,7 +77,7 @@ enum {
                                 CU's 160 KB LDS) are rendered by the LDS-resident persistent form of the BVH
                                 kernel; 0 (default): geometry stays in HBM/L2 (measured faster) */
     RT_OPTION_SUPERTILE = 2, /* edge, in 8x8-pixel tiles, of the super-tiles dealt round-robin to the
-                                XCDs by the global-memory kernels (default 8, 1..64) */
+                                XCDs by the global-memory kernels (default 2, 1..64) */
     RT_OPTION_TRAVERSAL = 3, /* RT_TRAVERSAL_*: which fast kernel renders (default AUTO: by scene size) */
     RT_OPTION_TIGHT_TREE = 4, /* 1 (default): uploads of large scenes also build a per-primitive tree that the
                                 staged pipeline walks as a filter in front of the reference's leaf-box rule
