@@ -72,7 +72,7 @@ def total_rays(stats):
 
 
 def orbit_cameras(sc, width, height, n):
-    """n cameras on a small orbit around the scene camera's own view (frame 0 = the scene camera)."""
+    """n cameras on a slow orbit around the scene camera's own view (frame 0 = the scene camera)."""
     from raytracing_amd import host
     cams = [sc.camera_for(width, height)]
     pos = sc.cameraData[0:3].astype(np.float64)
@@ -81,7 +81,8 @@ def orbit_cameras(sc, width, height, n):
     view = centre - pos
     target = pos + view / np.linalg.norm(view) * 8.0
     for k in range(1, n):
-        ang = 2 * np.pi * k / max(n, 8) * 0.25
+        ang = np.pi / 180.0 * k   # one degree per frame: a slow camera move, so that every frame of a step costs
+                                  # about what frame 0 (the scene's own camera, the N = 1 workload) costs
         rel = pos - target
         c, s = np.cos(ang), np.sin(ang)
         p = target + np.array([c * rel[0] + s * rel[2], rel[1], -s * rel[0] + c * rel[2]])

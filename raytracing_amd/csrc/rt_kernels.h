@@ -497,7 +497,7 @@ struct RenderArgs {
     DevScene scene;
     float cam[14];                      // frame 0
     float more_cams[MAX_BATCH - 1][14];  // frames 1 .. n_frames-1 of a batched launch
-    int n_frames;                       // block b renders frame b % n_frames, as that frame's block b / n_frames
+    int n_frames;                       // groups of 8 blocks go round the frames (select_frame)
     int blocks_per_frame;
     unsigned long long frame_stride;    // pixels between consecutive frames in every output plane
     PriorityRect prio[MAX_BATCH];       // per frame: super-tiles dealt out first (block_to_tile)
@@ -523,9 +523,13 @@ struct RenderArgs {
 // inside the frame.
 __device__ __forceinline__ int select_frame(const RenderArgs& a, int* block, float cam[14], PriorityRect* prio) {
     int f = 0;
-    if (a.n_frames > 1) {  // consecutive blocks go round the frames: every frame's priority columns start at once
-        f = *block % a.n_frames;  // (one frame after the other: a rank's share of an 8-GPU step 0.284 ms, interleaved 0.216)
-        *block /= a.n_frames;
+    if (a.n_frames > 1) {
+        // Groups of 8 consecutive blocks (one per XCD) go round the frames: every frame's priority columns
+        // start at once, and every frame is spread over all XCDs.  (One frame after the other: a rank's share
+        // of an 8-GPU step 0.284 ms, interleaved 0.216; block-by-block interleave would pin frame f to XCD f.)
+        const int g = *block >> 3;
+        f = g % a.n_frames;
+        *block = ((g / a.n_frames) << 3) | (*block & 7);
     }
 #pragma unroll
     for (int k = 0; k < 14; k++) {

@@ -29,7 +29,7 @@ def timed(fn, K=50):
 
 for world in (1, 2, 4, 8):
     sf = ShardedFrames(rt, w, h, 0, world, B.BAND_ROWS, world)
-    cams = [cam] * world
+    cams = B.orbit_cameras(sc, w, h, world)   # the bench's cameras: different frames, not one frame N times
     out = sf.local if world > 1 else sf.frames
     streams = [torch.cuda.Stream() for _ in range(4)]
 
@@ -38,7 +38,7 @@ for world in (1, 2, 4, 8):
         for s in streams:
             s.wait_stream(main)
         for f in range(world):
-            rt.render_device(cam, d, rgba8=out[f].data_ptr(), band_rows=B.BAND_ROWS, rank=0, world=world,
+            rt.render_device(cams[f], d, rgba8=out[f].data_ptr(), band_rows=B.BAND_ROWS, rank=0, world=world,
                              stream=streams[f % 4].cuda_stream)
         for s in streams:
             main.wait_stream(s)
