@@ -178,7 +178,8 @@ typedef struct rt_scene_info {
     int64_t bvh_nodes;      /* 64-byte nodes of the re-treed leaves (0 = not built)    */
     int64_t bvh_levels;     /* LDS stack entries per lane the BVH kernel reserves      */
     int64_t flags;          /* RT_SCENE_*                                              */
-    int64_t traversal;      /* RT_TRAVERSAL_* a default render (max_bounces 10) uses   */
+    int64_t traversal;      /* RT_TRAVERSAL_* a default render (max_bounces 10) uses; for a mid-sized scene under
+                               AUTO the measured verdict once there is one (RT_OPTION_WAVEFRONT_MIN_NODES)       */
     int64_t tight_nodes;    /* 64-byte nodes of the per-primitive tree (0 = not built) */
     int64_t tight_levels;   /* its depth                                               */
     int64_t unbounded_triangles; /* triangle slots with (nearly) collinear or coincident vertices as seen
