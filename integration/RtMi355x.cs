@@ -28,6 +28,12 @@ namespace OpenTK
             [In] float[] lights, int lightsLen);
 
         // replaces GL.Uniform1 of the camera (RayTracer.cs:955) + GL.DrawArrays (RayTracer.cs:135)
+        // device-resident outputs (IntPtr = device pointers); frames of one size, frameStride in pixels;
+        // up to 8 frames share a launch.  For hosts that keep frames in HBM (video encode, multi-GPU assembly).
+        [DllImport(Lib)] internal static extern int rt_render_frames_device(IntPtr ctx, [In] float[] cameras14xN, int nFrames,
+            int maxBounces, int flags, int bandRows, int rank, int world, long frameStride, IntPtr dRgb, IntPtr dRgba8,
+            IntPtr dPrimaryId, IntPtr dFinalId, IntPtr dBounces, IntPtr stream);
+
         [DllImport(Lib)] internal static extern int rt_render(IntPtr ctx, [In] float[] camera14, int maxBounces,
             [Out] float[] rgbOrNull, [Out] byte[] rgba8OrNull,
             [Out] int[] primaryIdOrNull, [Out] int[] finalIdOrNull, IntPtr statsOrNull);
