@@ -660,7 +660,7 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 // ---- large scenes: per-lane ordered traversal of the re-treed leaves, stacks in LDS ----------------
 // Same pixel mapping as k_render; dynamic LDS = BLOCK_WAVES * 64 lanes * bvh_levels dwords.
 #ifndef RT_BVH_WAVES_PER_EU
-#define RT_BVH_WAVES_PER_EU 4
+#define RT_BVH_WAVES_PER_EU 3
 #endif
 // UNB: see GeomBvhT.
 template <bool UNB>
