@@ -41,10 +41,14 @@ struct rt_ctx {
     // (tune_begin): scene size does not tell a triangle soup, where the staged pipeline is 1.8x faster at
     // 5.7 k nodes, from a field of meshes, where it is 3x slower at 18 k
     struct Tune {
-        long long key = -1;            // (upload, frame size, bounces) the measurements belong to
+        long long scene_serial = -1;   // (upload, frame size, bounces) the measurements belong to
+        int w = 0, rows = 0, bounces = -1;
         float ms[2] = {-1.0f, -1.0f};  // measured GPU time of [0] megakernel, [1] staged pipeline
+        int runs[2] = {0, 0};          // renders started with each: the first is a warm-up (first-use allocation of
+                                       // the path state, code load), the second is the one that is timed
         hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
         bool pending[2] = {false, false};
+        bool decided() const { return ms[0] >= 0 && ms[1] >= 0; }
     } tune;
     long long scene_serial = 0;
     bool prioritise = true;   // RT_PRIORITISE=0 (development): deal the tiles out in plain row-major order
@@ -331,6 +335,9 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
         (lights_len && !lights))
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // renders are asynchronous on caller streams (torch's are non-blocking: the copies below would not wait
+    // for them), and a buffer that does not grow is overwritten in place: drain the device first
+    HIP_TRY(ctx, hipDeviceSynchronize());
     ctx->has_scene = false;
 
     // everything decided on the host (rt_scene_prep.h): validation, cull preconditions, both trees
@@ -443,7 +450,8 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     inf.device_bytes = (int64_t)(flat.nodes.size() * 32 + (size_t)n_ts * 52 + (size_t)n_ss * 20 +
                                  (size_t)n_planes * 96 + (size_t)n_spheres * 48 + (size_t)n_triangles * 96 +
                                  (size_t)lights_len * 4);
-    ctx->lds_bytes = (geom_f4 - tri_off) * 16 + (size_t)LDS_BLOCK * std::max(bvh.levels, 1) * 4;
+    // k_render_bvh_lds strides its per-lane stacks by scene.bvh_levels (the deeper of the two trees)
+    ctx->lds_bytes = (geom_f4 - tri_off) * 16 + (size_t)LDS_BLOCK * std::max(s.bvh_levels, 1) * 4;
     inf.lds_scene_bytes = (int64_t)ctx->lds_bytes;
     inf.bvh_nodes = (int64_t)bvh.nodes.size();
     inf.bvh_levels = bvh.levels;
@@ -539,8 +547,8 @@ int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out) {
     out->traversal = pick_traversal(ctx, ctx->scene, 10);
     // a mid-sized scene under AUTO: the measured verdict once there is one (tune_begin)
     const rt_ctx::Tune& t = ctx->tune;
-    if (ctx->traversal == RT_TRAVERSAL_AUTO && out->traversal == RT_TRAVERSAL_BVH && (t.key >> 40) == ctx->scene_serial &&
-        t.ms[0] >= 0 && t.ms[1] >= 0 && ctx->scene.n_nodes >= ctx->wf_min_nodes)
+    if (ctx->traversal == RT_TRAVERSAL_AUTO && out->traversal == RT_TRAVERSAL_BVH && t.scene_serial == ctx->scene_serial &&
+        t.decided() && ctx->scene.n_nodes >= ctx->wf_min_nodes)
         out->traversal = t.ms[1] < t.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
     return RT_OK;
 }
@@ -585,11 +593,12 @@ static PriorityRect priority_rect(const DevScene& sc, const float* cam, int widt
     return pr;
 }
 
-// AUTO for mid-sized scenes: the first render of a (scene, frame size, bounces) runs the megakernel between
-// two events, the next one the staged pipeline, and from then on the faster of the two is used (results
-// are identical either way).  Nothing waits: a measurement is read when its events have completed, until
-// then renders keep the megakernel.  Returns the traversal to force (RT_TRAVERSAL_BVH / WAVEFRONT) or 0 for
-// "no opinion"; *timed = slot whose stop event tune_end must record, or -1.
+// AUTO for mid-sized scenes: the first two renders of a (scene, frame size, bounces) run the megakernel, the
+// next two the staged pipeline -- of each pair the first is a warm-up (it may include first-use allocation of
+// the path state and code load), the second runs between two events -- and from then on the faster of the
+// two is used (results are identical either way).  Nothing waits: a measurement is read when its events have
+// completed, until then renders keep the megakernel.  Returns the traversal to force (RT_TRAVERSAL_BVH /
+// WAVEFRONT) or 0 for "no opinion"; *timed = slot whose stop event tune_end must record, or -1.
 static int tune_begin(rt_ctx* ctx, int w, int local_rows, int max_bounces, hipStream_t st, int* timed) {
     *timed = -1;
     const DevScene& sc = ctx->scene;
@@ -597,10 +606,10 @@ static int tune_begin(rt_ctx* ctx, int w, int local_rows, int max_bounces, hipSt
         max_bounces > ctx->wf_max_bounces || sc.n_nodes < ctx->wf_min_nodes || sc.n_nodes >= ctx->wf_sure_nodes)
         return 0;
     rt_ctx::Tune& t = ctx->tune;
-    const long long key = (ctx->scene_serial << 40) ^ ((long long)w << 24) ^ ((long long)local_rows << 8) ^ max_bounces;
-    if (t.key != key) {
-        t.key = key;
+    if (t.scene_serial != ctx->scene_serial || t.w != w || t.rows != local_rows || t.bounces != max_bounces) {
+        t.scene_serial = ctx->scene_serial, t.w = w, t.rows = local_rows, t.bounces = max_bounces;
         t.ms[0] = t.ms[1] = -1.0f;
+        t.runs[0] = t.runs[1] = 0;
         t.pending[0] = t.pending[1] = false;
     }
     for (int k = 0; k < 2; k++)
@@ -612,13 +621,15 @@ static int tune_begin(rt_ctx* ctx, int w, int local_rows, int max_bounces, hipSt
     (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error
     for (int k = 0; k < 2; k++)
         if (t.ms[k] < 0 && !t.pending[k]) {
+            const int trav = k == 0 ? RT_TRAVERSAL_BVH : RT_TRAVERSAL_WAVEFRONT;
+            if (t.runs[k]++ == 0) return trav;  // warm-up, not timed
             for (int e = 0; e < 2; e++)
                 if (!t.ev[k][e] && hipEventCreate(&t.ev[k][e]) != hipSuccess) return 0;
             if (hipEventRecord(t.ev[k][0], st) != hipSuccess) return 0;
             *timed = k;
-            return k == 0 ? RT_TRAVERSAL_BVH : RT_TRAVERSAL_WAVEFRONT;
+            return trav;
         }
-    if (t.ms[0] >= 0 && t.ms[1] >= 0) return t.ms[1] < t.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
+    if (t.decided()) return t.ms[1] < t.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
     return RT_TRAVERSAL_BVH;
 }
 static void tune_end(rt_ctx* ctx, int timed, hipStream_t st) {
@@ -755,7 +766,7 @@ int rt_render_frames_device(rt_ctx* ctx, const float* cameras, int n_frames, int
         force = tune_begin(ctx, w, rt_local_rows(h, band_rows, rank, world), max_bounces, (hipStream_t)stream, &timed);
     else if (ctx->has_scene && ctx->tune.ms[0] >= 0 && ctx->tune.ms[1] >= 0 && !(flags & RT_RENDER_REFERENCE_ORDER) &&
              ctx->traversal == RT_TRAVERSAL_AUTO && ctx->scene.n_nodes >= ctx->wf_min_nodes && ctx->scene.n_nodes < ctx->wf_sure_nodes &&
-             (ctx->tune.key >> 40) == ctx->scene_serial && max_bounces <= ctx->wf_max_bounces)
+             ctx->tune.scene_serial == ctx->scene_serial && max_bounces <= ctx->wf_max_bounces)
         force = ctx->tune.ms[1] < ctx->tune.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;  // batches reuse a verdict
     for (int f0 = 0; f0 < n_frames; f0 += MAX_BATCH) {  // MAX_BATCH frames per launch
         const int n = std::min(MAX_BATCH, n_frames - f0);

@@ -37,7 +37,9 @@ def big_cases():
         {"id": "table_f0_960x540_d8", "scene": "TeapotTable", "depth": 8, "camera": _orbit(0, 960, 540)},
         {"id": "soup20k_640x360_d4", "scene": "Soup", "params": SOUP_MID, "depth": 4,
          "camera": _scene_cam(640, 360)},
-    ]
+        # BASELINE.json configs[4]: the TeapotTable orbit at its stated size and depth, four frames of the 256
+    ] + [{"id": f"table_f{f}_1920x1080_d8", "scene": "TeapotTable", "depth": 8, "camera": _orbit(f, 1920, 1080)}
+         for f in (0, 64, 128, 192)]
 
 
 def _unit(v):

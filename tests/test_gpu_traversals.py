@@ -333,8 +333,8 @@ def test_untraced_shadow_rays_leave_every_float_as_it_was(mode, label, rt_mode, 
 
 
 def test_auto_times_both_kernels_on_mid_sized_scenes(rt_mode, scene_of):
-    """Between 1000 and 100000 flattened nodes AUTO renders the first frame with the megakernel, the second
-    with the staged pipeline (both between events) and then keeps the faster: a triangle soup of 10 k
+    """Between 1000 and 100000 flattened nodes AUTO renders two frames with the megakernel, two with the staged
+    pipeline (of each pair the first is a warm-up, the second runs between events) and then keeps the faster: a triangle soup of 10 k
     triangles ends up on the staged pipeline, a field of teapots with three times as many nodes on the
     megakernel.  Every frame on the way is the same frame."""
     import torch
@@ -359,7 +359,7 @@ def test_auto_times_both_kernels_on_mid_sized_scenes(rt_mode, scene_of):
         assert 1000 <= rt.scene_info()["n_nodes"] < 100000 and rt.scene_info()["tight_nodes"] > 0
         cam = sc.camera_for(640, 360)
         frames = []
-        for _ in range(4):
+        for _ in range(6):
             out = torch.empty((360, 640, 4), dtype=torch.uint8, device="cuda")
             rt.render_device(cam, 4, rgba8=out.data_ptr(), stream=st)
             torch.cuda.synchronize()
@@ -396,3 +396,29 @@ def test_edge_scenes_in_every_traversal(mode, label, rt_mode, scene_of):
         _set_mode(rt, mode)
         out = _render(rt, sc, cam, depth)
         assert_frame_matches(out, oracle_render(sc, cam, depth), f"{what} {label}")
+
+
+@pytest.mark.parametrize("tight_everywhere", [False, True], ids=["leaf-tree-only", "with-tight-tree"])
+@pytest.mark.parametrize("name,depth", [("TestScene1", 10), ("TeapotTable", 8)])
+def test_lds_resident_kernel_matches_the_oracle(name, depth, tight_everywhere, rt_mode, scene_of):
+    """RT_OPTION_USE_LDS (k_render_bvh_lds, GeomBvhLds): the per-lane stacks are strided by the deeper of the
+    two trees, so the LDS allocation must be sized with it (a scene that also gets a tight tree used to
+    overflow it for the upper waves)."""
+    rt = rt_mode
+    sc = scene_of(name)
+    rt.set_option(rt.OPTION_TIGHT_TREE, 1)
+    rt.set_option(rt.OPTION_WAVEFRONT_MIN_NODES, 0 if tight_everywhere else 30000)
+    rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_BVH)
+    rt.set_option(rt.OPTION_USE_LDS, 1)
+    try:
+        for cam in (sc.camera_for(160, 90), sc.camera_for(333, 190)):   # 333x190: every wave of the 1024-thread groups works
+            ref = oracle_render(sc, cam, depth, threads=16)
+            out = _render(rt, sc, cam, depth)
+            assert_frame_matches(out, ref, f"{name} lds")
+        info = rt.scene_info()
+        assert 0 < info["lds_scene_bytes"] <= 160 * 1024, "the scene must actually fit, or the LDS kernel did not run"
+        assert (info["tight_nodes"] > 0) == tight_everywhere
+        if tight_everywhere:
+            assert info["tight_levels"] >= info["bvh_levels"]
+    finally:
+        rt.set_option(rt.OPTION_USE_LDS, 0)

@@ -67,6 +67,12 @@ def test_sample_rays(rt, scene_of):
     assert r["directions"].shape == (15, 3) and len(r["primary_id"]) == 15
     assert np.allclose(np.linalg.norm(r["directions"], axis=1), 1, atol=1e-6)
     assert (r["primary_id"] >= 0).any()
+    # the 15 ids are the oracle's for the same 15 x 1 frame of the same image plane
+    from helpers import oracle_render
+    cam15 = sc.camera_for(1280, 720).copy()
+    cam15[12], cam15[13] = 15.0, 1.0
+    ref = oracle_render(sc, cam15, 0, want=("primary_id",))
+    assert np.array_equal(r["primary_id"], ref["primary_id"][0])
     for d, i in zip(r["directions"], r["primary_id"]):
         t = debug.hit_distance(sc, r["origin"], d, int(i))
         assert t > 0
