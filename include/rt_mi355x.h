@@ -139,6 +139,25 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
                      int rank, int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id,
                      int32_t* d_final_id, int32_t* d_bounces, rt_stats* d_stats, void* stream);
 
+/* rt_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its frame buffer and
+ * every SSBO are allocated by the GL driver, RayTracer.cs:1007-1045).  Same arguments, same results as
+ * rt_render_device with flags = RT_RENDER_DEFAULT and no d_stats; the difference is where the staged
+ * pipeline (RT_TRAVERSAL_WAVEFRONT, large scenes) keeps its ray queues and per-path state: not in per-context
+ * buffers grown with hipMalloc on first use of a frame size, but in one fixed array of
+ * RT_NOALLOC_SCRATCH_BYTES inside the library's code object (each GPU the library runs on holds its own copy
+ * until the process ends).  This call performs no hipMalloc / hipFree / event creation.  A frame whose
+ * path state (72 B per local pixel + one byte per light for every pixel of the frame's 8x8 tiles) exceeds the
+ * array is rejected with RT_ERR_TOO_LARGE before anything is launched; the megakernels (small scenes) keep no
+ * such state and accept any size.  AUTO does not time mid-sized scenes here (a verdict rt_render_device
+ * measured earlier is reused, otherwise the megakernel renders).  All calls on one GPU share that GPU's
+ * array: calls that overlap on one GPU -- two contexts, or this context on two streams without the
+ * library's own chaining, which only orders renders of ONE context -- race. */
+#define RT_NOALLOC_SCRATCH_BYTES (96u << 20)
+int rt_render_device_noalloc(rt_ctx* ctx, const float camera[14], int max_bounces, int band_rows, int rank,
+                             int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id,
+                             int32_t* d_final_id, int32_t* d_bounces, void* stream);
+
 /* Batch form of rt_render_device for hosts that render several small frames per step (one rank of a
  * band-sharded multi-GPU render gets 1/world of every frame: a launch per frame would be latency bound).
  * cameras: n_frames x 14 floats (host), all of one width/height; frame f's pixels start

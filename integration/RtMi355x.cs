@@ -34,6 +34,12 @@ namespace OpenTK
             int maxBounces, int flags, int bandRows, int rank, int world, long frameStride, IntPtr dRgb, IntPtr dRgba8,
             IntPtr dPrimaryId, IntPtr dFinalId, IntPtr dBounces, IntPtr stream);
 
+        // rt_render_device for hosts that must not allocate while rendering (HIP graph capture, serving loops):
+        // the staged pipeline's path state lives in a fixed 96 MiB array inside the library; larger frames -> -6
+        [DllImport(Lib)] internal static extern int rt_render_device_noalloc(IntPtr ctx, [In] float[] camera14,
+            int maxBounces, int bandRows, int rank, int world, IntPtr dRgb, IntPtr dRgba8, IntPtr dPrimaryId,
+            IntPtr dFinalId, IntPtr dBounces, IntPtr stream);
+
         [DllImport(Lib)] internal static extern int rt_render(IntPtr ctx, [In] float[] camera14, int maxBounces,
             [Out] float[] rgbOrNull, [Out] byte[] rgba8OrNull,
             [Out] int[] primaryIdOrNull, [Out] int[] finalIdOrNull, IntPtr statsOrNull);

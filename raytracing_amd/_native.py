@@ -48,6 +48,7 @@ DEVICE_API = {
     "rt_upload_scene": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _VP, _I64, _VP, _I]),
     "rt_render": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "rt_render_device": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rt_render_device_noalloc": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rt_render_frames_device": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rt_local_rows": (_I, [_I, _I, _I, _I]),
     "rt_padded_rows": (_I, [_I, _I, _I]),

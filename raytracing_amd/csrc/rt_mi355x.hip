@@ -24,6 +24,13 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// Path state of the staged pipeline for rt_render_device_noalloc (include/rt_mi355x.h): a fixed array in
+// the code object instead of hipMalloc'ed buffers.  Every GPU the library is loaded on holds its own copy
+// at its own address until the process ends.  On the host the name is only a stand-in for that symbol:
+// the per-device address comes from hipGetSymbolAddress (rt_create) and is what kernels and memsets get.
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)RT_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
 }  // namespace
 
 struct rt_ctx {
@@ -66,6 +73,7 @@ struct rt_ctx {
     bool allow_lds = false;     // RT_OPTION_USE_LDS: opt-in, measured slower than the L2-resident walk
     // path state of the wavefront pipeline (rt_wavefront.h; grow only)
     DevBuf wf_org, wf_dir, wf_mult, wf_final, wf_list0, wf_list1, wf_blocked, wf_counters;
+    unsigned char* noalloc_scratch = nullptr;  // this device's address of `scratch` (hipGetSymbolAddress, rt_create)
     int wf_min_nodes = 1000;   // scenes with at least this many flat nodes get the tight tree and are candidates for
                                // the staged pipeline under AUTO (decided by measurement, tune_begin)
     int wf_sure_nodes = 100000;  // ... and from here on they take it without asking
@@ -147,7 +155,6 @@ int camera_size(const float* cam, int* w, int* h) {
 
 // Order a render that uses per-context device state behind the previous such render (see rt_ctx).
 int chain_begin(rt_ctx* ctx, hipStream_t st) {
-    if (!ctx->chain_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->chain_done, hipEventDisableTiming));
     if (ctx->chain_pending) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->chain_done, 0));
     return RT_OK;
 }
@@ -160,7 +167,32 @@ int chain_end(rt_ctx* ctx, hipStream_t st) {
 // The staged pipeline of rt_wavefront.h: per bounce one closest-hit stage, one shadow stage, one
 // shading stage, all on `st`; list sizes stay on the device (persistent / grid-stride kernels read
 // them), so the host never synchronises.
-int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st) {
+// Bytes of path state one render of the staged pipeline needs, laid out as consecutive 256-byte aligned
+// blocks: org | dir | mult | final (16 B per local pixel each), two index lists (4 B per pixel), one byte
+// per (work item of iteration 0, light), the per-iteration counters.
+struct WfLayout {
+    size_t org, dir, mult, final_, list0, list1, blocked, counters, total, n_counters;
+};
+WfLayout wf_layout(size_t n_px, size_t n0, int n_lights, int max_bounces) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    WfLayout l;
+    size_t at = 0;
+    l.org = at, at += up(n_px * 16);
+    l.dir = at, at += up(n_px * 16);
+    l.mult = at, at += up(n_px * 16);
+    l.final_ = at, at += up(n_px * 16);
+    l.list0 = at, at += up(n_px * 4);
+    l.list1 = at, at += up(n_px * 4);
+    l.blocked = at, at += up(n0 * (size_t)std::max(n_lights, 1));
+    l.n_counters = 4 * ((size_t)max_bounces + 2);
+    l.counters = at, at += up(l.n_counters * 4);
+    l.total = at;
+    return l;
+}
+
+// noalloc: the path state lives in this device's static `scratch` array (rt_render_device_noalloc) instead
+// of the context's grow-only buffers; a frame that does not fit is rejected, nothing is allocated.
+int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st, bool noalloc = false) {
     WfArgs a;
     a.scene = r.scene;
     if (!ctx->build_tight) a.scene.tight_root = 0u;
@@ -177,21 +209,36 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st) {
     a.n0 = (uint32_t)n0;
     a.rgb = r.rgb, a.rgba8 = r.rgba8, a.primary_id = r.primary_id, a.final_id = r.final_id, a.bounces = r.bounces;
     const size_t n_px = (size_t)r.width * r.local_rows;
-    const size_t n_counters = 4 * ((size_t)r.max_bounces + 2);
+    const WfLayout lay = wf_layout(n_px, n0, a.n_lights, r.max_bounces);
     int rc;
-    if ((rc = ensure(ctx, ctx->wf_org, n_px * 16)) || (rc = ensure(ctx, ctx->wf_dir, n_px * 16)) ||
-        (rc = ensure(ctx, ctx->wf_mult, n_px * 16)) || (rc = ensure(ctx, ctx->wf_final, n_px * 16)) ||
-        (rc = ensure(ctx, ctx->wf_list0, n_px * 4)) || (rc = ensure(ctx, ctx->wf_list1, n_px * 4)) ||
-        (rc = ensure(ctx, ctx->wf_blocked, n0 * (size_t)std::max(a.n_lights, 1))) ||
-        (rc = ensure(ctx, ctx->wf_counters, n_counters * 4)))
-        return rc;
-    a.org_t = (float4*)ctx->wf_org.p, a.dir_hit = (float4*)ctx->wf_dir.p;
-    a.mult_b = (float4*)ctx->wf_mult.p, a.final_ = (float4*)ctx->wf_final.p;
-    a.list[0] = (uint32_t*)ctx->wf_list0.p, a.list[1] = (uint32_t*)ctx->wf_list1.p;
-    a.blocked = (unsigned char*)ctx->wf_blocked.p;
-    a.counters = (uint32_t*)ctx->wf_counters.p;
+    if (noalloc) {
+        if (!ctx->noalloc_scratch) return fail(ctx, RT_ERR_DEVICE, "the static scratch array has no address on this device");
+        if (lay.total > NOALLOC_SCRATCH_BYTES)
+            return fail(ctx, RT_ERR_TOO_LARGE,
+                        "rt_render_device_noalloc: this frame needs " + std::to_string(lay.total) +
+                            " bytes of path state, the static scratch array holds " + std::to_string(NOALLOC_SCRATCH_BYTES));
+        unsigned char* const base = ctx->noalloc_scratch;
+        a.org_t = (float4*)(base + lay.org), a.dir_hit = (float4*)(base + lay.dir);
+        a.mult_b = (float4*)(base + lay.mult), a.final_ = (float4*)(base + lay.final_);
+        a.list[0] = (uint32_t*)(base + lay.list0), a.list[1] = (uint32_t*)(base + lay.list1);
+        a.blocked = base + lay.blocked;
+        a.counters = (uint32_t*)(base + lay.counters);
+    } else {
+        if ((rc = ensure(ctx, ctx->wf_org, n_px * 16)) || (rc = ensure(ctx, ctx->wf_dir, n_px * 16)) ||
+            (rc = ensure(ctx, ctx->wf_mult, n_px * 16)) || (rc = ensure(ctx, ctx->wf_final, n_px * 16)) ||
+            (rc = ensure(ctx, ctx->wf_list0, n_px * 4)) || (rc = ensure(ctx, ctx->wf_list1, n_px * 4)) ||
+            (rc = ensure(ctx, ctx->wf_blocked, n0 * (size_t)std::max(a.n_lights, 1))) ||
+            (rc = ensure(ctx, ctx->wf_counters, lay.n_counters * 4)))
+            return rc;
+        a.org_t = (float4*)ctx->wf_org.p, a.dir_hit = (float4*)ctx->wf_dir.p;
+        a.mult_b = (float4*)ctx->wf_mult.p, a.final_ = (float4*)ctx->wf_final.p;
+        a.list[0] = (uint32_t*)ctx->wf_list0.p, a.list[1] = (uint32_t*)ctx->wf_list1.p;
+        a.blocked = (unsigned char*)ctx->wf_blocked.p;
+        a.counters = (uint32_t*)ctx->wf_counters.p;
+    }
     if ((rc = chain_begin(ctx, st))) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, n_counters * 4, st));
+    // the only part of the state that must start at zero (the array keeps the previous call's contents)
+    HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, lay.n_counters * 4, st));
     const int trace_grid = ctx->n_cus * ctx->wf_waves_per_cu;
     const size_t lds = (size_t)64 * std::max(a.scene.bvh_levels, 1) * 4;
     const int shade_grid = ctx->n_cus * 8;
@@ -264,6 +311,17 @@ int rt_create(int device_id, rt_ctx** out) {
         const int t = atoi(v);
         if (t >= RT_TRAVERSAL_AUTO && t <= RT_TRAVERSAL_WAVEFRONT) ctx->traversal = t;
     }
+    // set-up that later calls must not repeat: the event that chains renders sharing per-context state, and
+    // this device's address of the static scratch array (device `device_id` is current here)
+    void* sym = nullptr;
+    if (hipEventCreateWithFlags(&ctx->chain_done, hipEventDisableTiming) != hipSuccess ||
+        hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)) != hipSuccess || !sym) {
+        (void)hipGetLastError();
+        if (ctx->chain_done) (void)hipEventDestroy(ctx->chain_done);
+        delete ctx;
+        return RT_ERR_DEVICE;
+    }
+    ctx->noalloc_scratch = (unsigned char*)sym;
     // the persistent kernel's ticket counter: zeroed once, never reset (rt_kernels.h)
     if (hipMalloc(&ctx->ticket.p, 256) != hipSuccess || hipMemset(ctx->ticket.p, 0, 256) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_render_bvh_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -643,7 +701,7 @@ static void tune_end(rt_ctx* ctx, int timed, hipStream_t st) {
 static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_t frame_stride, int max_bounces,
                          int flags, int band_rows, int rank, int world, float* d_rgb, uint8_t* d_rgba8,
                          int32_t* d_primary_id, int32_t* d_final_id, int32_t* d_bounces, rt_stats* d_stats,
-                         void* stream, int force_trav = 0) {
+                         void* stream, int force_trav = 0, bool noalloc = false) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "rt_upload_scene has not succeeded on this context");
     int w, h;
@@ -695,7 +753,7 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
         (size_t)((w + 7) / 8) * ((a.local_rows + 7) / 8) * 64 * (size_t)std::max(a.scene.lights_len / 6, 1) >= 0xFFFFFFF0ull)
         trav = RT_TRAVERSAL_BVH;
     const bool use_wf = trav == RT_TRAVERSAL_WAVEFRONT, use_bvh = trav == RT_TRAVERSAL_BVH;
-    const bool use_lds = use_bvh && !(flags & RT_RENDER_GLOBAL_MEMORY) && ctx->allow_lds && ctx->lds_capable && ctx->ticket.p;
+    const bool use_lds = use_bvh && !noalloc && !(flags & RT_RENDER_GLOBAL_MEMORY) && ctx->allow_lds && ctx->lds_capable && ctx->ticket.p;
     if (n_frames > 1 && ((flags & RT_RENDER_REFERENCE_ORDER) || use_wf || use_lds || (size_t)n_blocks * n_frames > 0x7FFFFFFFull)) {
         // one frame per launch for these paths
         for (int f = 0; f < n_frames; f++) {
@@ -703,7 +761,7 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
             const int rc = render_frames(ctx, camera + 14 * f, 1, 0, max_bounces, flags, band_rows, rank, world,
                                          d_rgb ? d_rgb + 3 * off : nullptr, d_rgba8 ? d_rgba8 + 4 * off : nullptr,
                                          d_primary_id ? d_primary_id + off : nullptr, d_final_id ? d_final_id + off : nullptr,
-                                         d_bounces ? d_bounces + off : nullptr, d_stats, stream, force_trav);
+                                         d_bounces ? d_bounces + off : nullptr, d_stats, stream, force_trav, noalloc);
             if (rc != RT_OK) return rc;
         }
         return RT_OK;
@@ -711,7 +769,7 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
     if (flags & RT_RENDER_REFERENCE_ORDER)
         hipLaunchKernelGGL(k_render<true>, dim3(n_blocks), dim3(64 * BLOCK_WAVES), 0, st, a);
     else if (use_wf)
-        return launch_wavefront(ctx, a, st);
+        return launch_wavefront(ctx, a, st, noalloc);
     else if (use_lds) {
         // LDS-resident persistent kernel: one workgroup per CU; each of its waves draws one ticket
         // past the end, so the launch consumes exactly n_tickets + n_waves tickets
@@ -746,6 +804,20 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
                                  d_primary_id, d_final_id, d_bounces, d_stats, stream, force);
     tune_end(ctx, timed, (hipStream_t)stream);
     return rc;
+}
+
+int rt_render_device_noalloc(rt_ctx* ctx, const float camera[14], int max_bounces, int band_rows, int rank, int world,
+                             float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id, int32_t* d_final_id,
+                             int32_t* d_bounces, void* stream) {
+    // The traversal is the one rt_render_device would take, without its timing of mid-sized scenes (a verdict
+    // measured earlier is honoured): nothing here creates events, buffers or anything else.
+    int force = 0;
+    if (ctx && ctx->has_scene && ctx->traversal == RT_TRAVERSAL_AUTO && ctx->tune.scene_serial == ctx->scene_serial &&
+        ctx->tune.ms[0] >= 0 && ctx->tune.ms[1] >= 0 && ctx->scene.n_nodes >= ctx->wf_min_nodes &&
+        ctx->scene.n_nodes < ctx->wf_sure_nodes && max_bounces <= ctx->wf_max_bounces)
+        force = ctx->tune.ms[1] < ctx->tune.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
+    return render_frames(ctx, camera, 1, 0, max_bounces, RT_RENDER_DEFAULT, band_rows, rank, world, d_rgb, d_rgba8,
+                         d_primary_id, d_final_id, d_bounces, nullptr, stream, force, true);
 }
 
 int rt_render_frames_device(rt_ctx* ctx, const float* cameras, int n_frames, int max_bounces, int flags, int band_rows,

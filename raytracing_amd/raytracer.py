@@ -159,6 +159,20 @@ class RayTracer:
                                                int(rank), int(world), vp(rgb), vp(rgba8), vp(primary_id),
                                                vp(final_id), vp(bounces), vp(stats), vp(stream)))
 
+    NOALLOC_SCRATCH_BYTES = 96 << 20
+
+    def render_device_noalloc(self, cameraData, max_bounces, *, rgb=None, rgba8=None, primary_id=None, final_id=None,
+                              bounces=None, band_rows=None, rank=0, world=1, stream=0):
+        """rt_render_device_noalloc: as render_device, but the staged pipeline's path state lives in the
+        library's static device array (no hipMalloc); oversized frames raise RtError(RT_ERR_TOO_LARGE)."""
+        cam = np.ascontiguousarray(cameraData, dtype=np.float32)
+        if band_rows is None:
+            band_rows = int(cam[13])
+        vp = lambda v: C.c_void_p(int(v)) if v else None  # noqa: E731
+        self._check(self._lib.rt_render_device_noalloc(self._ctx, N.ptr(cam), int(max_bounces), int(band_rows),
+                                                       int(rank), int(world), vp(rgb), vp(rgba8), vp(primary_id),
+                                                       vp(final_id), vp(bounces), vp(stream)))
+
     def render_frames_device(self, cameras, max_bounces, frame_stride, *, rgb=None, rgba8=None, primary_id=None,
                              final_id=None, bounces=None, reference_order=False, band_rows=None, rank=0, world=1,
                              stream=0):

@@ -1,0 +1,82 @@
+"""GPU: rt_render_device_noalloc (static scratch array instead of hipMalloc'ed path state) reproduces
+rt_render_device bit for bit, on two calls in a row, the second with a smaller frame; oversized frames are
+rejected before anything runs.  Collected last (file name) so that a failure here hides no other test."""
+import numpy as np
+import pytest
+import torch
+
+from raytracing_amd.raytracer import RtError
+
+pytestmark = pytest.mark.gpu
+
+RT_ERR_TOO_LARGE = -6
+
+
+def _render(rt, fn, cam, depth, w, h, **kw):
+    dev = torch.device("cuda", 0)
+    out = {"rgb": torch.full((h, w, 3), -7.0, dtype=torch.float32, device=dev),
+           "rgba8": torch.zeros((h, w, 4), dtype=torch.uint8, device=dev),
+           "primary_id": torch.full((h, w), -9, dtype=torch.int32, device=dev),
+           "final_id": torch.full((h, w), -9, dtype=torch.int32, device=dev),
+           "bounces": torch.full((h, w), -9, dtype=torch.int32, device=dev)}
+    fn(cam, depth, stream=torch.cuda.current_stream().cuda_stream, **{k: v.data_ptr() for k, v in out.items()}, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _same(a, b, what):
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), f"{what}: plane {k} differs"
+
+
+@pytest.mark.parametrize("scene,params,depth", [("Soup", [8000, 80, 8], 4), ("TeapotTable", None, 8)])
+def test_noalloc_equals_render_device_twice(rt, scene_of, scene, params, depth):
+    sc = scene_of(scene, params)
+    rt.SendPrimitivesToShader(sc)
+    rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_WAVEFRONT)   # the path whose kernels use the scratch
+    try:
+        for (w, h) in [(320, 180), (123, 77)]:   # the second call is smaller: stale state of the first must not leak
+            cam = sc.camera_for(w, h)
+            ref = _render(rt, rt.render_device, cam, depth, w, h)
+            got = _render(rt, rt.render_device_noalloc, cam, depth, w, h)
+            _same(got, ref, f"{scene} {w}x{h}")
+            assert (ref["final_id"] >= 0).any() and ref["bounces"].max() >= 1   # a real picture with bounces
+        # band-sharded, as a rank of a multi-GPU render would call it
+        w, h = 160, 90
+        cam = sc.camera_for(w, h)
+        rows = rt.local_rows(h, 8, 1, 3)
+        ref = _render(rt, rt.render_device, cam, depth, w, rows, band_rows=8, rank=1, world=3)
+        got = _render(rt, rt.render_device_noalloc, cam, depth, w, rows, band_rows=8, rank=1, world=3)
+        _same(got, ref, f"{scene} bands")
+    finally:
+        rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)
+
+
+def test_noalloc_megakernel_path_and_size_limit(rt, scene_of):
+    sc = scene_of("Soup", [8000, 80, 8])
+    rt.SendPrimitivesToShader(sc)
+    # the megakernel keeps no path state: any size goes through
+    rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_BVH)
+    try:
+        cam = sc.camera_for(200, 120)
+        _same(_render(rt, rt.render_device_noalloc, cam, 4, 200, 120), _render(rt, rt.render_device, cam, 4, 200, 120),
+              "megakernel")
+        # the staged pipeline needs 72 B per pixel + 8 lights: 2048 x 1024 = 160 MiB > 96 MiB
+        rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_WAVEFRONT)
+        w, h = 2048, 1024
+        assert (72 + 8) * w * h > rt.NOALLOC_SCRATCH_BYTES
+        canary = torch.full((16,), 0x5A, dtype=torch.uint8, device="cuda")   # far too small: must never be written
+        with pytest.raises(RtError) as e:
+            rt.render_device_noalloc(sc.camera_for(w, h), 4, rgba8=canary.data_ptr(),
+                                     stream=torch.cuda.current_stream().cuda_stream)
+        assert e.value.code == RT_ERR_TOO_LARGE and "scratch" in str(e.value)
+        torch.cuda.synchronize()
+        assert (canary == 0x5A).all()
+        # the largest frame that fits still renders, and equals the allocating entry point
+        w, h = 1280, 720
+        cam = sc.camera_for(w, h)
+        a = _render(rt, rt.render_device_noalloc, cam, 4, w, h)
+        b = _render(rt, rt.render_device, cam, 4, w, h)
+        _same(a, b, "1280x720")
+    finally:
+        rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)
