@@ -1,37 +1,52 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s of the per-pixel ray-casting hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--strong]
 
-Workload (BASELINE.json configs[1]): TeapotScene -- assets/teapot via OBJImportHelper + RTree over
-the mirror floor with TestScene1's six lights -- 1920x1080, shadows + 1 reflection bounce.
-A step renders world-size frames of a camera orbit; every frame is cut into 8-row bands dealt
-round-robin to the ranks, rendered into HBM, and the whole batch is assembled on every rank with ONE
-RCCL all-gather per step (double buffered, so the exchange of step s-1 overlaps the render of step
-s).  Per-GPU work per step is therefore one frame's worth at any N ("weak").
-Rays are counted by the reference's rule (primary + executed mirror bounces + shadow rays) with
-the reference-order kernel outside the timed region; the count is identical to the oracle's.
+`--gpus N` with N > 1 starts its own N ranks (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE set, rendezvous
+on 127.0.0.1) unless it already runs under a launcher (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...` sets WORLD_SIZE), in which case it is one of the ranks.  The parent never touches the GPU.
+
+Headline workload: TeapotScene -- BASELINE.json configs[1]'s scene (assets/teapot via OBJImportHelper + RTree
+over the mirror floor, TestScene1's six lights, shadows + 1 reflection bounce) at 3840x2160, the size
+BASELINE.json's metric ("ms/frame at 4K") and north_star's target ("teapot scene at 4K") are quoted on.
+configs[1]'s own 1920x1080 frame, configs[0] (TestScene1 720p), configs[2] (Soup1M 4K: HBM-side traversal)
+and configs[4]'s frame (TeapotTable 1080p depth 8) are measured in the same run under "extra", each with its
+own roofline object.
+
+Steps.  weak (default): a step renders N frames of a camera orbit; every frame is cut into 8-row bands dealt
+round-robin to the N ranks, every rank renders its bands of all N frames in one launch, and ONE RCCL
+all-to-all per step delivers frame f's bands to rank f, which restores scanline order: N concurrent gathers,
+one root each, so per-GPU work AND per-GPU traffic stay one frame's worth at any N.  The exchange of step s-1
+overlaps the render of step s (double buffered, at most one collective in flight).
+strong (`--strong`): ONE frame per step, its bands split over the N ranks and gathered on rank 0
+(BASELINE.json configs[3]: `--strong --workload soup1m_8k_d4`).
+
+Rays are counted by the reference's rule (primary + executed mirror bounces + shadow rays) with the
+reference-order kernel outside the timed region; the count is identical to the oracle's.  `rays_traced` is
+what the fast kernels actually trace: they leave out shadow rays whose light term is an exact zero
+either way (same pixels), which the reference traces.
 
 One JSON line is printed by rank 0 (contract in the task description) with two extra objects:
-  roofline      algorithmic bytes of the reference algorithm per launch / measured kernel time
-  cpu_baseline  the CPU oracle ("port") timed single-threaded on a bounded sample of the same frame
+  roofline      the bound that applies to the dominant kernel (<= 1 by construction), see roofline_of()
+  cpu_baseline  the CPU oracle ("port") timed on a bounded sample of the same frame
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 KERNEL_OF = {1: "k_render<false> (wave-cooperative walk)", 2: "k_render_bvh (per-lane BVH, LDS stacks)",
              3: "k_wf_closest + k_wf_any + k_wf_shade per bounce (wavefront pipeline, whole frame)"}
-FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2.4 GHz
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
 BAND_ROWS = 8  # one 8x8 tile row per band: finest interleave of sky / mesh / floor rows over the ranks
 
 WORKLOADS = {
@@ -44,6 +59,8 @@ WORKLOADS = {
     "soup1m_8k_d4": ("Soup", [1_000_000, 10_000, 8], 7680, 4320, 4),
     "soup100k_1080p_d4": ("Soup", [100_000, 1_000, 8], 1920, 1080, 4),
 }
+HEADLINE = "teapot_4k_d1"
+EXTRAS = ["teapot_1080p_d1", "testscene1_720p_d10", "teapottable_1080p_d8", "soup100k_1080p_d4", "soup1m_4k_d4"]
 
 
 def parse_workload(spec):
@@ -62,7 +79,7 @@ def algorithmic_bytes(stats, width, height):
 
 def algorithmic_flops(stats):
     """flops of the reference algorithm per frame (27 per box test, 30 per sphere, 75 per
-    triangle, 8 per plane test) -- the VALU-side figure for cache-resident scenes."""
+    triangle, 8 per plane test) -- the VALU-side figure."""
     return (27 * stats["node_tests"] + 30 * stats["sphere_tests"] + 75 * stats["triangle_tests"] +
             8 * stats["plane_tests"])
 
@@ -71,8 +88,13 @@ def total_rays(stats):
     return stats["primary_rays"] + stats["secondary_rays"] + stats["shadow_rays"]
 
 
+def traced_rays(stats):
+    return total_rays(stats) - stats.get("shadow_rays_zero_term", 0)
+
+
 def orbit_cameras(sc, width, height, n):
     """n cameras on a slow orbit around the scene camera's own view (frame 0 = the scene camera)."""
+    import numpy as np
     from raytracing_amd import host
     cams = [sc.camera_for(width, height)]
     pos = sc.cameraData[0:3].astype(np.float64)
@@ -104,12 +126,13 @@ def device_stats(rt, torch, cam, depth):
 
 
 def time_single(rt, torch, cam, depth, width, height, steps, warmup):
-    """ms per frame of the fast kernel, device-resident RGBA8 output, HIP events on the launch stream."""
+    """ms per frame of the fast kernel, device-resident RGBA8 output, HIP events on the launch stream.
+    (>= 5 warm-up frames: AUTO decides between its two kernels over the first four frames of a mid-sized scene.)"""
     out = torch.empty((height, width, 4), dtype=torch.uint8, device="cuda")
     s = torch.cuda.current_stream()
-    for _ in range(warmup):
+    for _ in range(max(warmup, 5)):
         rt.render_device(cam, depth, rgba8=out.data_ptr(), stream=s.cuda_stream)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s)
     for _ in range(steps):
@@ -119,9 +142,77 @@ def time_single(rt, torch, cam, depth, width, height, steps, warmup):
     return e0.elapsed_time(e1) / steps
 
 
+_profiles = None
+
+
+def profile_of(workload):
+    """Counters of a committed rocprofv3 --pmc run of this workload (profiles/traffic.json), or {}."""
+    global _profiles
+    if _profiles is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                _profiles = json.load(f)
+        except (OSError, ValueError):
+            _profiles = {}
+    return _profiles.get(workload, {})
+
+
+def roofline_of(workload, stats, width, height, ms, traversal, share=1.0):
+    """The bound of the dominant kernel as a fraction <= 1.
+
+    One "launch" = one frame (the megakernels: one kernel; the staged pipeline: its 3 x (max_bounces + 1) kernels
+    issued back to back), `ms` = its duration measured live with HIP events on the launch stream.
+    Scenes that live in L2 (every reference-sized scene) are bound by VALU issue: achieved = flops of the REFERENCE
+    algorithm (27 per box test, 30 per sphere, 75 per triangle, 8 per plane test; every candidate
+    tested) / ms against the fp32 vector peak, plus -- from the committed PMC pass -- the share of VALU issue slots
+    in use and the active lanes per instruction.  Soup1M (113 MB of hot nodes and triangles, nothing of it in
+    L2) is bound by the memory side: achieved = bytes that crossed the L2 -> fabric boundary per frame (PMC,
+    gfx950-corrected: 2 x FETCH_SIZE + WRITE_SIZE) / ms against the HBM peak.  The byte count of the reference
+    algorithm is kept beside it (`reference_algorithm_bytes_per_launch`): the kernels cull, order and stop early,
+    so they move far fewer bytes than it, and dividing it by the time exceeds every physical bandwidth.
+    share: the part of a frame one launch renders (1/N on a rank of a strong-scaled frame)."""
+    prof = profile_of(workload)
+    alg_flops = algorithmic_flops(stats) * share
+    alg_bytes = algorithmic_bytes(stats, width, height) * share
+    tf = alg_flops / (ms * 1e-3) / 1e12
+    traffic = prof.get("hbm_bytes_per_launch")
+    valu = {"achieved_tflops": round(tf, 2), "peak_tflops": FP32_VECTOR_PEAK_TF, "frac": round(tf / FP32_VECTOR_PEAK_TF, 4),
+            "algorithmic_flops_per_launch": int(alg_flops)}
+    if prof.get("SQ_INSTS_VALU"):
+        # issued VALU wave-instructions x 4 cycles each, over the SIMD-cycles of the launch
+        valu["issue_occupancy"] = round(prof["SQ_INSTS_VALU"] * share * 4 / (N_SIMD * ms * 1e-3 * CLOCK_HZ), 3)
+    if prof.get("SQ_THREAD_CYCLES_VALU") and prof.get("SQ_ACTIVE_INST_VALU"):
+        valu["active_lanes"] = round(prof["SQ_THREAD_CYCLES_VALU"] / (64.0 * prof["SQ_ACTIVE_INST_VALU"]), 3)
+    hbm = None
+    if traffic:
+        gbs = traffic * share / (ms * 1e-3) / 1e9
+        hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    memory_bound = bool(prof.get("memory_bound")) and hbm is not None
+    r = {"bound": "hbm" if memory_bound else "valu"}
+    if memory_bound:
+        r.update(hbm)
+        r["valu"] = valu
+    else:
+        r.update({"achieved": valu["achieved_tflops"], "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": valu["frac"]})
+        for k in ("issue_occupancy", "active_lanes", "algorithmic_flops_per_launch"):
+            if k in valu:
+                r[k] = valu[k]
+        if hbm:
+            r["hbm"] = hbm
+    r["traffic"] = int(traffic * share) if traffic else None
+    r["kernel"] = KERNEL_OF.get(traversal, "?")
+    r["kernel_ms"] = round(ms, 4)
+    r["reference_algorithm_bytes_per_launch"] = int(alg_bytes)
+    if prof.get("source"):
+        r["pmc_source"] = prof["source"]
+    return r
+
+
 def cpu_baseline(sc, cam, depth, width, height, budget_s=12.0):
     """The oracle (a C++ port of the reference algorithm; the reference itself cannot run here),
-    single-threaded, on evenly spaced full rows of the same frame, sized to ~budget_s of CPU."""
+    single-threaded, on evenly spaced full rows of the same frame, sized to ~budget_s of CPU; then the same
+    code with an OpenMP row loop on every core this process may use."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
@@ -150,10 +241,11 @@ def cpu_baseline(sc, cam, depth, width, height, budget_s=12.0):
         what = f"the whole {width}x{height} frame, {reps} passes"
     rays, dt = rows(ys, 1)
     one = rays / dt / 1e6
-    # the same sample on all host cores (one row per call, rows spread over an OpenMP team is not
-    # possible with 1-row regions, so the multi-core figure renders a band per call)
+    # every core this process may run on (the GPU box exports OMP_NUM_THREADS = its CPU share; honour it)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 16) if os.environ.get("OMP_NUM_THREADS") is None else min(cores, int(os.environ["OMP_NUM_THREADS"]))
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        cores = max(1, min(cores, int(os.environ["OMP_NUM_THREADS"])))
+
     def frame_all():
         r = O.render(sc.spheresData.view(O.SPHERE_DT), sc.planesData.view(O.PLANE_DT), sc.trianglesData.view(O.TRI_DT),
                      sc.AccelerationStructureData, sc.lightsData, cam, depth, region=(0, 0, width, height),
@@ -175,7 +267,7 @@ def cpu_baseline(sc, cam, depth, width, height, budget_s=12.0):
             return c["primary"] + c["secondary"] + c["shadow"]
     frame_all()                             # the thread team starts outside the timed region
     rays_all, passes, t0 = 0, 0, time.perf_counter()
-    while passes == 0 or time.perf_counter() - t0 < 3.0:
+    while passes == 0 or time.perf_counter() - t0 < 5.0:
         rays_all += frame_all()
         passes += 1
     dt_all = time.perf_counter() - t0
@@ -184,7 +276,8 @@ def cpu_baseline(sc, cam, depth, width, height, budget_s=12.0):
             "sample": f"{what} ({rays} rays, {dt:.1f} s, C++ restatement of the reference algorithm, "
                       f"1 thread, row by row)",
             "all_cores": {"value": round(allc, 3), "cores": cores,
-                          "sample": f"{all_what}, {passes} passes, OpenMP row loop, {dt_all:.1f} s"}}
+                          "sample": f"{all_what}, {passes} passes, OpenMP row loop over {cores} threads "
+                                    f"(every core this process may use), {dt_all:.1f} s"}}
 
 
 def dbg(*a):
@@ -192,18 +285,77 @@ def dbg(*a):
         print(f"[rank {os.environ.get('RANK', '0')}]", *a, file=sys.stderr, flush=True)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N fresh rank processes (this process has not
+    touched the GPU and never does), wait for them, return the worst exit code.  Rank 0's stdout is ours."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0:
+                        rc = rc or code
+                        for q in pending:          # one rank failed: the others would wait in a collective forever
+                            procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def measure_extra(rt, torch, host, name):
+    """One single-GPU workload outside the contract's timed region: ms/frame, rays and its roofline."""
+    sn, pr, w, h, d = WORKLOADS[name]
+    t_build = time.perf_counter()
+    s2 = host.make_scene(sn, params=pr)
+    t_build = time.perf_counter() - t_build
+    t_up = time.perf_counter()
+    rt.SendPrimitivesToShader(s2)
+    t_up = time.perf_counter() - t_up
+    cam = s2.camera_for(w, h)
+    st = device_stats(rt, torch, cam, d)
+    big = name.startswith("soup1m")
+    ms = time_single(rt, torch, cam, d, w, h, 5 if big else 20, 5)
+    trav = rt.scene_info()["traversal"]
+    return {"ms_per_frame": round(ms, 4), "Mrays_per_s": round(total_rays(st) / ms / 1e3, 1),
+            "rays": total_rays(st), "rays_traced": traced_rays(st),
+            "scene_build_s": round(t_build, 2), "upload_s": round(t_up, 2),
+            "roofline": roofline_of(name, st, w, h, ms, trav)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="teapot_1080p_d1", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
+    ap.add_argument("--strong", action="store_true",
+                    help="ONE frame per step split over the ranks and gathered on rank 0 (default: weak, N frames per step)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU workloads")
+    ap.add_argument("--no-soup1m", action="store_true", help="skip the 1M-triangle soup among the extras")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--verify", action="store_true", help="check the assembled frames against whole-frame renders")
-    ap.add_argument("--soup1m", action="store_true", help="include the 1M-triangle soup in the extras")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))   # before anything touches the GPU
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from raytracing_amd import RayTracer, host
@@ -213,42 +365,51 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # BENCH_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the N > 1 code path on a one-GPU box
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
+    n_ranks_rccl = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        n_ranks_rccl = dist.get_world_size()
 
     dbg("process group up")
     scene_name, params, W, H, depth = WORKLOADS[args.workload]
     sc = host.make_scene(scene_name, params=params)
     rt = RayTracer(local_rank)
     rt.SendPrimitivesToShader(sc)
-    cams = orbit_cameras(sc, W, H, world)
+    n_frames = 1 if args.strong else world
+    cams = orbit_cameras(sc, W, H, n_frames)
 
-    # rays per step: every frame of the batch, counted by the reference-order kernel (untimed)
+    # rays per step: every frame of the step, counted by the reference-order kernel (untimed)
     frame_stats = [device_stats(rt, torch, cam, depth) for cam in cams]
     rays_per_step = sum(total_rays(s) for s in frame_stats)
+    traced_per_step = sum(traced_rays(s) for s in frame_stats)
     dbg("stats done", rays_per_step)
 
-    # ---- timed region: K steps, each = `world` band-sharded frames + ONE all-gather for the batch ----
+    # ---- timed region: K steps, each = this rank's bands of n_frames frames + ONE collective ----
     stream = torch.cuda.current_stream()
-    bufs = [P.ShardedFrames(rt, W, H, rank, world, BAND_ROWS, len(cams)) for _ in range(2)]  # double buffered
+    assemble = "root" if args.strong else "owner"
+    bufs = [P.ShardedFrames(rt, W, H, rank, world, BAND_ROWS, n_frames, assemble=assemble) for _ in range(2)]  # double buffered
+    if bufs[0].staged and rank == 0:
+        print(f"bench: backend {backend} cannot move device tensors in this collective; staging through host memory "
+              f"(rehearsal only)", file=sys.stderr)
+    for _ in range(6):  # AUTO settles on a kernel for this (scene, local frame size, bounces) before anything is timed
+        bufs[0].render(cams, depth)
+        torch.cuda.synchronize()
 
     step_no = [0]
 
     def step():
-        # step s renders while the all-gather of step s-1 is in flight on RCCL's stream
+        # step s renders while the exchange of step s-1 is in flight on RCCL's stream
         b, other = bufs[step_no[0] % 2], bufs[(step_no[0] + 1) % 2]
-        b.finish()               # this buffer's previous exchange: scanline order, on every rank
+        b.finish()               # this buffer's previous exchange: scanline order on the frame's owner
         b.render(cams, depth)
         other.wait_gather()      # at most one collective in flight (it has overlapped this step's render)
         b.gather_async()
@@ -267,7 +428,6 @@ def main():
         step()
         dbg("warmup step")
     drain()
-    dbg("drained")
     fence()
     dbg("fenced")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -280,18 +440,18 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     dbg("timed region done", elapsed)
-    if args.verify:  # the assembled frames of the last step equal whole-frame renders on this rank
-        last = bufs[(step_no[0] - 1) % 2].frames
-        for f, cam in enumerate(cams):
+    if args.verify:  # the frames this rank assembled in the last step equal whole-frame renders
+        last = bufs[(step_no[0] - 1) % 2]
+        for f, frame in last.owned_frames():
             ref = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
-            rt.render_device(cam, depth, rgba8=ref.data_ptr(), stream=stream.cuda_stream)
+            rt.render_device(cams[f], depth, rgba8=ref.data_ptr(), stream=stream.cuda_stream)
             torch.cuda.synchronize()
-            if not torch.equal(ref, last[f]):
+            if not torch.equal(ref, frame):
                 raise SystemExit(f"rank {rank}: assembled frame {f} differs from the single-GPU render")
-        dbg("verified", len(cams), "assembled frames")
-    kernel_ms = e0.elapsed_time(e1) / (args.steps * len(cams))  # per render launch, on the launch stream
+        dbg("verified", [f for f, _ in last.owned_frames()])
+    kernel_ms = e0.elapsed_time(e1) / args.steps  # per render launch (one per step), on the launch stream
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -300,90 +460,68 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_per_step / (elapsed / args.steps) / 1e6
         st0 = frame_stats[0]
-        # one launch renders 1/world of a frame; algorithmic bytes scale the same way
-        alg_bytes = sum(algorithmic_bytes(s, W, H) for s in frame_stats) / len(frame_stats) / world
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        alg_flops = sum(algorithmic_flops(s) for s in frame_stats) / len(frame_stats) / world
-        valu_tf = alg_flops / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if world == 1 and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
+        trav = rt.scene_info()["traversal"]
+        # one launch renders this rank's bands of every frame of the step: n_frames / world frames' worth
+        mean_stats = {k: sum(s[k] for s in frame_stats) / len(frame_stats) for k in st0}
         result = {
             "metric": "Mrays/s (primary+shadow+secondary)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (teapot mesh fixture of the reference asset, builder-defined scene, orbit cameras)",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (mesh fixtures of the reference assets / seeded soup, builder-defined scenes, orbit cameras)",
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H,
                        "max_bounces": depth, "lights": sc.n_lights, "triangles": len(sc.trianglesData),
-                       "frames_per_step": len(cams), "rays_per_step": rays_per_step,
-                       "sharding": f"{BAND_ROWS}-row bands round-robin over {world} rank(s), "
-                                   f"one RCCL all-gather per step" if world > 1 else "single GPU, whole frame"},
-            "ray_breakdown_frame0": {k: st0[k] for k in ("primary_rays", "secondary_rays", "shadow_rays")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": KERNEL_OF.get(rt.scene_info()["traversal"], "?"), "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "algorithmic bytes of the REFERENCE algorithm (SURVEY 8d: every candidate "
-                                 "tested, no distance cull); the kernel culls and orders, so it is credited with "
-                                 "more bytes than it moves (frac can exceed 1) -- `traffic` is what HBM saw.  "
-                                 "This scene is L2-resident: the binding limit is VALU issue, see `valu`",
-                         "valu": {"algorithmic_flops_per_launch": int(alg_flops),
-                                  "achieved_tflops": round(valu_tf, 2), "peak_tflops": FP32_VECTOR_PEAK_TF,
-                                  "frac": round(valu_tf / FP32_VECTOR_PEAK_TF, 4),
-                                  "note": "peak counts FMA as 2 flops; the canonical arithmetic forbids "
-                                          "contraction, so half of it is reachable"}},
+                       "spheres": len(sc.spheresData), "frames_per_step": n_frames, "rays_per_step": rays_per_step,
+                       "rays_traced_per_step": traced_per_step,
+                       "rays_note": "value counts the reference's rays (every shadow ray of its algorithm); "
+                                    "rays_traced leaves out the shadow rays whose light term is an exact zero "
+                                    "either way, which the fast kernels do not trace (identical pixels)",
+                       "sharding": ("single GPU, whole frame" if world == 1 else
+                                    f"{BAND_ROWS}-row bands round-robin over {world} ranks; " +
+                                    ("one frame per step gathered on rank 0" if args.strong else
+                                     f"{world} frames per step, one all-to-all: frame f assembled on rank f"))},
+            "n_ranks_rccl": n_ranks_rccl, "backend": backend if world > 1 else None,
+            "ms_per_frame": round(ms_per_step / n_frames, 4),
+            "ray_breakdown_frame0": {k: st0[k] for k in ("primary_rays", "secondary_rays", "shadow_rays",
+                                                         "shadow_rays_zero_term")},
+            "roofline": roofline_of(args.workload, mean_stats, W, H, kernel_ms, trav, share=n_frames / world),
         }
 
     # ---- N = 1 only: extra workloads and the CPU baseline (outside the contract's timed region) ----
     if world == 1 and rank == 0:
         if not args.no_extras:
             extras = {}
-            names = ["teapot_4k_d1", "testscene1_720p_d10", "teapottable_1080p_d8", "soup100k_1080p_d4"]
-            if args.soup1m:
-                names.append("soup1m_4k_d4")
-            for name in names:
-                if name == args.workload:
+            for name in EXTRAS:
+                if name == args.workload or (args.no_soup1m and name.startswith("soup1m")):
                     continue
-                sn, pr, w, h, d = WORKLOADS[name]
-                t_build = time.perf_counter()
-                s2 = host.make_scene(sn, params=pr)
-                t_build = time.perf_counter() - t_build
-                rt.SendPrimitivesToShader(s2)
-                cam = s2.camera_for(w, h)
-                st = device_stats(rt, torch, cam, d)
-                big = name.startswith("soup")
-                ms = time_single(rt, torch, cam, d, w, h, 3 if big else 20, 2 if big else 3)  # >= 2 warm-up frames: AUTO times both kernels
-                ab = algorithmic_bytes(st, w, h)
-                extras[name] = {"traversal": KERNEL_OF.get(rt.scene_info()["traversal"], "?").split(" ")[0],
-                                "ms_per_frame": round(ms, 4), "Mrays_per_s": round(total_rays(st) / ms / 1e3, 1),
-                                "rays": total_rays(st), "algorithmic_GBps": round(ab / ms / 1e6, 1),
-                                "scene_build_s": round(t_build, 2)}
+                extras[name] = measure_extra(rt, torch, host, name)
             rt.SendPrimitivesToShader(sc)
-            # the headline workload as a throughput job: 8 orbit frames per launch (rt_render_frames_device).
-            # A single 1080p frame leaves ~0.1 ms of ramp and tail per launch on the table; `value` above is
-            # the single-frame figure (one step = one frame, as the reference draws them).
-            batch = np.stack(orbit_cameras(sc, W, H, 8))
-            out8 = torch.empty((8, H, W, 4), dtype=torch.uint8, device="cuda")
+            # configs[1]'s frame as a throughput job: 8 orbit frames per launch (rt_render_frames_device).
+            # A single 1080p frame leaves ~0.06 ms of ramp and tail per launch on the table.
+            sn, pr, w8, h8, d8 = WORKLOADS["teapot_1080p_d1"]
+            s8 = sc if sn == scene_name else host.make_scene(sn, params=pr)
+            rt.SendPrimitivesToShader(s8)
+            batch = np.stack(orbit_cameras(s8, w8, h8, 8))
+            out8 = torch.empty((8, h8, w8, 4), dtype=torch.uint8, device="cuda")
             s = torch.cuda.current_stream()
             for _ in range(3):
-                rt.render_frames_device(batch, depth, H * W, rgba8=out8.data_ptr(), stream=s.cuda_stream)
+                rt.render_frames_device(batch, d8, h8 * w8, rgba8=out8.data_ptr(), stream=s.cuda_stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
             for _ in range(10):
-                rt.render_frames_device(batch, depth, H * W, rgba8=out8.data_ptr(), stream=s.cuda_stream)
+                rt.render_frames_device(batch, d8, h8 * w8, rgba8=out8.data_ptr(), stream=s.cuda_stream)
             e1.record(s)
             torch.cuda.synchronize()
             ms8 = e0.elapsed_time(e1) / 10
-            rays8 = sum(total_rays(device_stats(rt, torch, c, depth)) for c in batch)
-            extras[args.workload + "_8_frames_per_launch"] = {
+            rays8 = sum(total_rays(device_stats(rt, torch, c, d8)) for c in batch)
+            extras["teapot_1080p_d1_8_frames_per_launch"] = {
                 "ms_per_launch": round(ms8, 4), "ms_per_frame": round(ms8 / 8, 4),
                 "Mrays_per_s": round(rays8 / ms8 / 1e3, 1), "rays": rays8}
+            rt.SendPrimitivesToShader(sc)
             result["extra"] = extras
         if not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(sc, cams[0], depth, W, H)
             result["gpu_over_cpu_1thread"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+            result["gpu_over_cpu_all_cores"] = round(result["value"] / result["cpu_baseline"]["all_cores"]["value"], 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
     rt.close()

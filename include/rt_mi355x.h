@@ -53,7 +53,11 @@ typedef struct rt_stats {
     uint64_t plane_tests;       /* IntersectPlane calls on planes[]                           */
     uint64_t triangle_tests;    /* IntersectTriangle calls                                    */
     uint64_t material_fetches;  /* accepted closer hits in FindClosestIntersection            */
-    uint64_t reserved[7];
+    uint64_t shadow_rays_zero_term; /* not a reference counter: those of shadow_rays whose light term is an exact
+                                   zero whichever way the ray ends (light behind the surface, no highlight).  The
+                                   reference traces them, the fast kernels do not (same pixels):
+                                   rays the fast kernels trace = primary + secondary + shadow - this           */
+    uint64_t reserved[6];
 } rt_stats;
 
 /* Render flags */

@@ -326,6 +326,30 @@ struct Worker {
         int primary_id, final_id, bounces;
     };
 
+    // Bookkeeping only (ORC_C_ZERO_TERM), no effect on any pixel: would this light's term below add exactly
+    // nothing whichever way its shadow ray ends?  Same expressions as the shading code of Shade(); true when every
+    // component is a zero and the diffuse colour has no sign bit (x + 0 == x except for x = -0).
+    static bool sign(float v) {
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        return (u >> 31) != 0;
+    }
+    static bool TermIsZero(const Hit& h, bool mirror, V3 rayDirection, V3 L, float distanceToLight, V3 lightColor) {
+        V3 term;
+        if (mirror) {
+            term = 1.0f / (distanceToLight * distanceToLight) * lightColor * h.color * max0(dot(h.normal, L));
+        } else {
+            V3 n = h.normal;
+            if (dot(n, rayDirection) > 0.0f) n = -n;
+            V3 vectorR = normalize(L - 2 * dot(L, n) * n);
+            float a = max0(dot(n, L)), dr = max0(dot(rayDirection, vectorR));
+            if (!(dr == 0.0f && h.specularity > 0.0f)) return false;  // powf(0, s) == 0 needs s > 0
+            term = 1.0f / (distanceToLight * distanceToLight) * lightColor * (h.color * a + h.spec * 0.0f);
+        }
+        return term.x == 0.0f && term.y == 0.0f && term.z == 0.0f && !sign(h.color.x) && !sign(h.color.y) &&
+               !sign(h.color.z);
+    }
+
     // raytracer_fs.glsl:300-425.  px,py are gl_FragCoord.xy (pixel centre, origin bottom-left).
     Pixel Shade(const float* camera, float px, float py, int maxBounces) {
         const float epsilon = 0.001f;
@@ -358,6 +382,8 @@ struct Worker {
                     V3 lightPos = ld3(s->lights + l);
                     float distanceToLight = length(lightPos - hitPos);
                     V3 shadowRayDirection = normalize(lightPos - hitPos);
+                    if (TermIsZero(h, true, rayDirection, shadowRayDirection, distanceToLight, ld3(s->lights + l + 3)))
+                        c[ORC_C_ZERO_TERM]++;
                     if (!ObjectInWayOfLight(distanceToLight, hitPos, shadowRayDirection)) {
                         V3 lightColor = ld3(s->lights + l + 3);
                         combinedColor = combinedColor + 1.0f / (distanceToLight * distanceToLight) * lightColor *
@@ -390,6 +416,8 @@ struct Worker {
             V3 lightPos = ld3(s->lights + l);
             float distanceToLight = length(lightPos - hitPos);
             V3 shadowRayDirection = normalize(lightPos - hitPos);
+            if (TermIsZero(h, false, rayDirection, shadowRayDirection, distanceToLight, ld3(s->lights + l + 3)))
+                c[ORC_C_ZERO_TERM]++;
             if (!ObjectInWayOfLight(distanceToLight, hitPos, shadowRayDirection)) {
                 V3 lightColor = ld3(s->lights + l + 3);
                 if (dot(n, rayDirection) > 0.0f) n = -n;

@@ -40,6 +40,9 @@ enum {
     ORC_C_MAX_STACK = 9,    /* deepest traversal stack seen (shader's fixed size is 100)   */
     ORC_C_MAX_SPH_CAND = 10,/* longest sphere candidate list (shader's fixed size is 100)  */
     ORC_C_MAX_TRI_CAND = 11,/* longest triangle candidate list (shader's fixed size 500)   */
+    ORC_C_ZERO_TERM = 12,   /* NOT a property of the reference: those of ORC_C_SHADOW whose light term is an exact
+                               zero whether or not the ray is blocked (the shadow rays the HIP fast kernels leave
+                               untraced); lets the tests check that count on the CPU                              */
     ORC_N_COUNTERS = 16
 };
 

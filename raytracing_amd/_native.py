@@ -23,11 +23,11 @@ TRIANGLE_DT = np.dtype([("PointA", "<f4", 3), ("padding0", "<f4"), ("PointB", "<
 assert SPHERE_DT.itemsize == 48 and PLANE_DT.itemsize == 64 and TRIANGLE_DT.itemsize == 96
 
 STATS_FIELDS = ["primary_rays", "secondary_rays", "shadow_rays", "node_tests", "refs_read", "sphere_tests",
-                "plane_tests", "triangle_tests", "material_fetches"]
+                "plane_tests", "triangle_tests", "material_fetches", "shadow_rays_zero_term"]
 
 
 class rt_stats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in STATS_FIELDS] + [("reserved", C.c_uint64 * 7)]
+    _fields_ = [(n, C.c_uint64) for n in STATS_FIELDS] + [("reserved", C.c_uint64 * 6)]
 
 
 class rt_scene_info(C.Structure):

@@ -9,7 +9,7 @@
 namespace rtd {
 
 // counter slots of the reference-order kernel (order of rt_stats)
-enum { C_PRIMARY, C_SECONDARY, C_SHADOW, C_NODE, C_REFS, C_SPHERE, C_PLANE, C_TRI, C_MAT, C_N };
+enum { C_PRIMARY, C_SECONDARY, C_SHADOW, C_NODE, C_REFS, C_SPHERE, C_PLANE, C_TRI, C_MAT, C_ZERO_TERM, C_N };
 
 // ------------------------------------------------------------------------------------------
 // Stackless fixed-order traversal (rt_flatten.h).  kinds: bit 0 = test sphere leaves,
@@ -448,7 +448,9 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
         if (sf.diffuse.x != 0 || sf.diffuse.y != 0 || sf.diffuse.z != 0) {
             // fast kernels: a light whose term is exactly zero either way needs no shadow ray
             const V3 combined = mirror_diffuse_term(S, sf, hitPos, [&](int, const LightRay& lr) {
-                if (!REF && light_term_is_zero(sf, true, rayDirection, lr)) return true;
+                const bool zero = light_term_is_zero(sf, true, rayDirection, lr);
+                if (REF && zero) cnt[C_ZERO_TERM]++;  // the reference traces it; counted for rays_traced (bench)
+                if (!REF && zero) return true;
                 return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt);
             });
             finalColor = finalColor + combined * mult;
@@ -469,7 +471,9 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
     }
     const V3 hitPos = rayOrigin + h.t * rayDirection;
     const V3 combined = phong_term(S, sf, hitPos, rayDirection, [&](int, const LightRay& lr) {
-        if (!REF && light_term_is_zero(sf, false, rayDirection, lr)) return true;
+        const bool zero = light_term_is_zero(sf, false, rayDirection, lr);
+        if (REF && zero) cnt[C_ZERO_TERM]++;
+        if (!REF && zero) return true;
         return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt);
     });
     out.rgb = finalColor + combined * mult;

@@ -69,35 +69,63 @@ def assemble_frames(gathered, height, band_rows, world):
 
 
 class ShardedFrames:
-    """Per-rank state of a batch of band-sharded RGBA8 frames that travel in ONE all-gather.
+    """Per-rank state of a batch of band-sharded RGBA8 frames that travel in ONE collective per step.
 
-    A 1080p band set is ~1 MB per rank: one collective per frame is latency bound on xGMI, so a step
-    that renders n_frames frames renders every frame's local bands first (alternating over a few HIP
-    streams, so the tail of one small launch overlaps the head of the next) and exchanges them together."""
+    A 1080p band set is ~1 MB per rank: one collective per frame is latency bound on xGMI, so a step that
+    renders n_frames frames renders every frame's local bands with one launch (up to 8 frames; more go out
+    in batches over a few HIP streams) and exchanges them together.  `assemble` says where frames end up:
 
-    def __init__(self, rt, width, height, rank, world, band_rows, n_frames, group=None, device=None, n_streams=4):
+      "owner"  n_frames == world: frame f is assembled on rank f -- world concurrent gathers, one root each,
+               as ONE all-to-all.  Every rank sends and receives (world-1)/world of a frame per step, whatever
+               the world size (xGMI is point to point: each peer's share travels its own link).
+      "root"   every frame is assembled on rank 0 (one gather): the strong-scaling form, one frame per step.
+      "all"    every rank gets every frame (one all-gather); traffic per rank grows with world."""
+
+    def __init__(self, rt, width, height, rank, world, band_rows, n_frames, group=None, device=None, n_streams=4,
+                 assemble="all"):
         self.rt, self.W, self.H, self.F = rt, int(width), int(height), int(n_frames)
         self.rank, self.world, self.band, self.group = rank, world, int(band_rows), group
+        if assemble not in ("all", "owner", "root"):
+            raise ValueError("assemble must be 'all', 'owner' or 'root'")
+        if assemble == "owner" and self.F != world:
+            raise ValueError("assemble='owner' needs one frame per rank")
+        self.assemble = assemble
         dev = device if device is not None else torch.device("cuda", rt.device_id)
         self.pr = padded_rows(self.H, self.band, world)
         self.local = torch.zeros((self.F, self.pr, self.W, 4), dtype=torch.uint8, device=dev)
-        self.gathered = torch.empty((world, self.F, self.pr, self.W, 4), dtype=torch.uint8, device=dev)
-        self.frames = torch.empty((self.F, self.H, self.W, 4), dtype=torch.uint8, device=dev)
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(min(n_streams, self.F))] if self.F > 1 else []
+        n_mine = {"all": self.F, "owner": 1, "root": self.F if rank == 0 else 0}[assemble]
+        self.n_mine = n_mine
+        # what arrives here: [source rank][frame of mine][padded rows][W] (owner: one frame, root: rank 0 only)
+        self.gathered = torch.empty((world, max(n_mine, 1), self.pr, self.W, 4), dtype=torch.uint8, device=dev)
+        self.frames = torch.empty((max(n_mine, 1), self.H, self.W, 4), dtype=torch.uint8, device=dev)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(min(n_streams, self.F))] if self.F > 8 else []
         self.pending = None
+        self.ready = False
+        # backends that cannot move device tensors in this collective (gloo rehearsals) stage through the host
+        self.staged = world > 1 and dist.is_initialized() and dist.get_backend(group) != "nccl" and dev.type != "cpu"
+        self.on_gpu = dev.type != "cpu"   # host tensors: only the tests' stand-in renderer (no GPU in the container)
+
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream if self.on_gpu else 0
+
+    def owned_frames(self):
+        """(frame index, assembled [H, W, 4] tensor) of the frames this rank holds after finish()."""
+        if self.assemble == "owner" and self.world > 1:
+            return [(self.rank, self.frames[0])]
+        return [(f, self.frames[f]) for f in range(self.n_mine)]
 
     def render(self, cameras, max_bounces):
         """Launch all frames' local bands; on return the current stream waits for them.  The frames go to
         the library in batches of 8 (one launch each for the megakernels, rt_render_frames_device), batches
         alternating over the streams so that the tail of one launch overlaps the head of the next."""
-        main = torch.cuda.current_stream()
         out = self.local if self.world > 1 else self.frames  # a single rank renders straight into the frames
         stride = out.stride(0) // 4  # pixels between consecutive frames
         batches = [(f0, min(f0 + 8, self.F)) for f0 in range(0, self.F, 8)]
         if len(batches) == 1 or not self.streams:
             self.rt.render_frames_device(cameras[:self.F], max_bounces, stride, rgba8=out.data_ptr(), band_rows=self.band,
-                                         rank=self.rank, world=self.world, stream=main.cuda_stream)
+                                         rank=self.rank, world=self.world, stream=self._stream())
             return
+        main = torch.cuda.current_stream()
         for s in self.streams:
             s.wait_stream(main)
         for k, (f0, f1) in enumerate(batches):
@@ -107,11 +135,27 @@ class ShardedFrames:
         for s in self.streams:
             main.wait_stream(s)
 
+    def _collective(self, recv, send, async_op):
+        flat_send = send.view(-1)
+        if self.assemble == "all":
+            return dist.all_gather_into_tensor(recv.view(-1), flat_send, group=self.group, async_op=async_op)
+        if self.assemble == "owner":   # chunk d of `send` (frame d's bands) goes to rank d
+            return dist.all_to_all_single(recv.view(-1), flat_send, group=self.group, async_op=async_op)
+        parts = [recv[r].view(-1) for r in range(self.world)] if self.rank == 0 else None
+        return dist.gather(flat_send, parts, dst=0, group=self.group, async_op=async_op)
+
     def gather_async(self):
-        if self.world > 1:
-            self.pending = dist.all_gather_into_tensor(
-                self.gathered.view(self.world * self.F * self.pr, self.W, 4),
-                self.local.view(self.F * self.pr, self.W, 4), group=self.group, async_op=True)
+        if self.world == 1:
+            return
+        if self.staged:   # rehearsal path: device -> host, collective on host tensors, host -> device
+            send = self.local.cpu()
+            recv = torch.empty(self.gathered.shape, dtype=torch.uint8)
+            self._collective(recv, send, False)
+            if self.n_mine:
+                self.gathered.copy_(recv)
+            self.ready = True
+            return
+        self.pending = self._collective(self.gathered, self.local, True)
 
     def wait_gather(self):
         """Make the current stream wait for this buffer's exchange (if one is in flight)."""
@@ -121,12 +165,13 @@ class ShardedFrames:
             self.ready = True
 
     def finish(self):
-        """Wait for the exchange of this buffer (if any) and restore scanline order on every rank."""
+        """Wait for the exchange of this buffer (if any) and restore scanline order where frames are assembled."""
         self.wait_gather()
-        if getattr(self, "ready", False):
+        if self.ready:
             self.ready = False
-            self.rt.unpermute_frames(self.gathered.data_ptr(), self.frames.data_ptr(), 4, self.W, self.H, self.band,
-                                     self.world, self.F, stream=torch.cuda.current_stream().cuda_stream)
+            if self.n_mine:
+                self.rt.unpermute_frames(self.gathered.data_ptr(), self.frames.data_ptr(), 4, self.W, self.H, self.band,
+                                         self.world, self.n_mine, stream=self._stream())
         return self.frames
 
 

@@ -22,7 +22,7 @@ TRI_DT = np.dtype([("a", "<f4", 3), ("pad0", "<f4"), ("b", "<f4", 3), ("pad1", "
 assert SPHERE_DT.itemsize == 48 and PLANE_DT.itemsize == 64 and TRI_DT.itemsize == 96
 
 COUNTER_NAMES = ["primary", "secondary", "shadow", "node_tests", "refs_read", "sphere_tests", "plane_tests",
-                 "tri_tests", "material", "max_stack", "max_sph_cand", "max_tri_cand"]
+                 "tri_tests", "material", "max_stack", "max_sph_cand", "max_tri_cand", "zero_term"]
 
 _lib = None
 

@@ -87,3 +87,86 @@ def test_two_rank_gloo_frame_assembly(w, h, band):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+# ---- ShardedFrames (bench.py's exchange) with a stand-in renderer: the three assembly modes over gloo --------
+class _OracleRenderer:
+    """Stand-in for RayTracer on a host without a GPU: same two methods ShardedFrames calls, same buffers (host
+    tensors addressed by data_ptr), rows rendered by the oracle, un-permute by the torch index path."""
+    device_id = 0
+
+    def __init__(self, sc, w, h):
+        self.sc, self.w, self.h = sc, w, h
+
+    @staticmethod
+    def _view(ptr, n):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(ptr))
+
+    def render_frames_device(self, cameras, max_bounces, frame_stride, *, rgba8, band_rows, rank, world, stream=0):
+        from helpers import oracle_render
+        rows = P.global_rows_of(self.h, band_rows, rank, world)
+        for f, cam in enumerate(cameras):
+            dst = self._view(rgba8 + f * frame_stride * 4, len(rows) * self.w * 4).reshape(len(rows), self.w, 4)
+            for lr, y in enumerate(rows):
+                dst[lr] = oracle_render(self.sc, cam, max_bounces, threads=1, region=(0, int(y), self.w, int(y) + 1),
+                                        want=("rgba8",))["rgba8"][0]
+
+    def unpermute_frames(self, gathered, out, elem_size, width, height, band_rows, world, n_frames, stream=0):
+        pr = P.padded_rows(height, band_rows, world)
+        g = torch.from_numpy(self._view(gathered, world * n_frames * pr * width * 4).reshape(world, n_frames, pr, width, 4))
+        o = self._view(out, n_frames * height * width * 4).reshape(n_frames, height, width, 4)
+        o[:] = P.assemble_frames(g, height, band_rows, world).numpy()
+
+
+def _sharded_worker(rank, world, port, mode, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_render
+    from raytracing_amd import host
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w, h, band, depth = 40, 27, 4, 2
+        sc = host.make_scene("TestScene1")
+        n_frames = 1 if mode == "root" else world
+        cams = [host.camera_orbit(40 * f, 256, w, h) for f in range(n_frames)]
+        bufs = [P.ShardedFrames(_OracleRenderer(sc, w, h), w, h, rank, world, band, n_frames, assemble=mode,
+                                device=torch.device("cpu")) for _ in range(2)]
+        assert not bufs[0].staged
+        for step in range(3):            # bench.py's double-buffered step
+            b, other = bufs[step % 2], bufs[(step + 1) % 2]
+            b.finish()
+            b.render(cams, depth)
+            other.wait_gather()
+            b.gather_async()
+        ok = True
+        for b in bufs:
+            b.finish()
+            owned = b.owned_frames()
+            expect = {"all": list(range(n_frames)), "owner": [rank], "root": [0] if rank == 0 else []}[mode]
+            ok = ok and [f for f, _ in owned] == expect
+            for f, frame in owned:
+                full = oracle_render(sc, cams[f], depth, threads=2, want=("rgba8",))["rgba8"]
+                ok = ok and bool(np.array_equal(frame.numpy(), full))
+        q.put((rank, ok))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["owner", "root", "all"])
+def test_two_rank_gloo_sharded_frames(mode):
+    """bench.py's step on two ranks: "owner" = one all-to-all, frame f assembled on rank f (weak scaling);
+    "root" = one frame gathered on rank 0 (strong scaling); "all" = all-gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, True), (1, True)]
