@@ -72,6 +72,21 @@ enum {
  * device_id: HIP device ordinal (one context per GPU; multi-GPU hosts create one per rank). */
 int rt_create(int device_id, rt_ctx** out);
 void rt_destroy(rt_ctx* ctx);
+/* One context over several GPUs of one node (the reference's host draws one frame per call on one
+ * GPU, RayTracer.cs:125-137, and has nothing comparable).  device_ids[0] is the root.  On the returned context
+ *   rt_upload_scene  replicates the scene on every device (validated and flattened once on the host),
+ *   rt_render        cuts the frame into 8-row bands dealt round-robin to the devices, renders every device's
+ *                    bands on its own stream, gathers them on the root over RCCL (grouped ncclSend/ncclRecv: each
+ *                    peer's bands travel its own xGMI link) and restores scanline order there: one call = one
+ *                    finished frame, as the reference's draw; results are those of a single-GPU context,
+ *   rt_set_option / rt_get_scene_info / rt_last_error / rt_destroy act on the whole context.
+ * The device-resident entry points (rt_render_device*, rt_unpermute_*) address the ROOT device only.
+ * Single process, one host thread; RCCL (librccl.so) is loaded when the first such context is created
+ * (ncclCommInitAll).  A list that names one device several times is accepted for testing: the ranks are then
+ * played on that GPU and the bands move with device-to-device copies instead of RCCL. */
+int rt_create_multi(const int* device_ids, int n_devices, rt_ctx** out);
+/* Devices of a context (1 for rt_create) and whether its gather goes over RCCL. */
+int rt_multi_info(const rt_ctx* ctx, int* n_devices, int* uses_rccl);
 /* The reference only prints GL info logs (RayTracer.cs:53-56, 1054). */
 const char* rt_last_error(const rt_ctx* ctx);
 

@@ -13,6 +13,10 @@ namespace OpenTK
         const string Lib = "rt_mi355x";   // librt_mi355x.so next to the executable or on LD_LIBRARY_PATH
 
         [DllImport(Lib)] internal static extern int rt_create(int deviceId, out IntPtr ctx);
+        // one context over several GPUs of the node: rt_upload_scene replicates the scene, rt_render splits the frame
+        // into 8-row bands over the devices and gathers them on deviceIds[0] over RCCL; same pixels as one GPU
+        [DllImport(Lib)] internal static extern int rt_create_multi([In] int[] deviceIds, int nDevices, out IntPtr ctx);
+        [DllImport(Lib)] internal static extern int rt_multi_info(IntPtr ctx, out int nDevices, out int usesRccl);
         [DllImport(Lib)] internal static extern void rt_destroy(IntPtr ctx);
         [DllImport(Lib)] internal static extern IntPtr rt_last_error(IntPtr ctx);   // UTF-8, owned by ctx
         // tuning knobs, results never depend on them (include/rt_mi355x.h RT_OPTION_*):
@@ -58,6 +62,7 @@ namespace OpenTK
         internal static void Render(Scenes.IScene scene, float[] cameraData, SphereStruct[] sphereData,
                                     PlaneStruct[] planeData, TriangleStruct[] triangleData, float[] lights, string path)
         {
+            // all GPUs of the node: RtMi355x.rt_create_multi(new[] {0, 1, 2, 3, 4, 5, 6, 7}, 8, out ctx) -- nothing else changes
             RtMi355x.Check(IntPtr.Zero, RtMi355x.rt_create(0, out IntPtr ctx));
             try
             {

@@ -42,6 +42,8 @@ class rt_scene_info(C.Structure):
 _VP, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 DEVICE_API = {
     "rt_create": (_I, [_I, C.POINTER(_VP)]),
+    "rt_create_multi": (_I, [C.POINTER(_I), _I, C.POINTER(_VP)]),
+    "rt_multi_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
     "rt_destroy": (None, [_VP]),
     "rt_last_error": (C.c_char_p, [_VP]),
     "rt_set_option": (_I, [_VP, _I, _I]),

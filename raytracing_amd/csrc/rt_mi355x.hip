@@ -33,8 +33,10 @@ static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 }  // namespace
 
+struct rt_multi;
 struct rt_ctx {
     int device = 0;
+    rt_multi* multi = nullptr;  // rt_create_multi: this context is the root of a multi-GPU context (rt_multi.h)
     std::string error;
     bool has_scene = false;
     int supertile = 2;  // workgroup tiles per super-tile edge: 2 x 8-pixel tiles = 16 px (block_to_tile).  With the priority
@@ -260,6 +262,13 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st, bool noal
 
 }  // namespace
 
+// rt_multi.h (included at the end of this file)
+static int multi_upload(rt_ctx* root, const rtp::Prepared& prep, const void* spheres, int n_spheres, const void* planes,
+                        int n_planes, const void* triangles, int n_triangles, const float* lights, int lights_len);
+static int multi_render(rt_ctx* root, const float* camera, int max_bounces, float* rgb, uint8_t* rgba8, int32_t* primary_id,
+                        int32_t* final_id, rt_stats* stats);
+static void multi_release(rt_ctx* root);
+
 extern "C" {
 
 int rt_local_rows(int height, int band_rows, int rank, int world) {
@@ -337,6 +346,7 @@ int rt_create(int device_id, rt_ctx** out) {
 
 void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->multi) multi_release(ctx);  // the other devices' contexts, streams, communicators
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->chain_done) (void)hipEventDestroy(ctx->chain_done);
@@ -383,44 +393,24 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
 
 const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
 
-int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
-                    const void* triangles, int n_triangles, const float* accel, int64_t accel_len,
-                    const float* lights, int lights_len) {
-    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
-    if (n_spheres < 0 || n_planes < 0 || n_triangles < 0 || accel_len < 0 || lights_len < 0 || lights_len % 6 != 0)
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "negative count or lights_len not a multiple of 6");
-    if ((n_spheres && !spheres) || (n_planes && !planes) || (n_triangles && !triangles) || (accel_len && !accel) ||
-        (lights_len && !lights))
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
+// Device half of rt_upload_scene for ONE context: the prepared host structures (rt_scene_prep.h) and the caller's
+// arrays go to ctx's GPU.  A multi-GPU context prepares once and runs this for every device (the scene is
+// replicated).
+static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* spheres, int n_spheres, const void* planes,
+                           int n_planes, const void* triangles, int n_triangles, const float* lights, int lights_len) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // renders are asynchronous on caller streams (torch's are non-blocking: the copies below would not wait
     // for them), and a buffer that does not grow is overwritten in place: drain the device first
     HIP_TRY(ctx, hipDeviceSynchronize());
     ctx->has_scene = false;
-
-    // everything decided on the host (rt_scene_prep.h): validation, cull preconditions, both trees
-    rtp::Prepared prep;
-    std::string err;
-    rtp::Options opt;
-    opt.build_tight = ctx->build_tight, opt.tight_min_nodes = ctx->wf_min_nodes;
-    int rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
-                          accel_len, opt, &prep, &err);
-    if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
     const rtf::Flat& flat = prep.flat;
     const rtb::Bvh& bvh = prep.bvh;
-    rtb::Bvh& tight = prep.tight;
+    const rtb::Bvh& tight = prep.tight;
     const std::vector<int32_t>&tri_slot_leaf = prep.tri_slot_leaf, &sphere_slot_leaf = prep.sphere_slot_leaf;
     const bool contained = prep.contained;
     const float* extent = prep.extent;
     const float tight_e = prep.tight_e;
-    {  // the tight nodes follow the leaf tree's in one array: inner refs become indices of that array
-        const uint32_t base = (uint32_t)bvh.nodes.size();
-        for (rtb::Node& nd : tight.nodes) {
-            if (!(nd.ref0 & rtb::LEAF)) nd.ref0 += base;
-            if (!(nd.ref1 & rtb::LEAF)) nd.ref1 += base;
-        }
-    }
-
+    int rc;
     if ((rc = upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48))) return rc;
     if ((rc = upload(ctx, ctx->planes_aos, planes, (size_t)n_planes * 64))) return rc;
     if ((rc = upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96))) return rc;
@@ -523,6 +513,36 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     ctx->has_scene = true;
     ctx->scene_serial++;
     return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
+                    const void* triangles, int n_triangles, const float* accel, int64_t accel_len,
+                    const float* lights, int lights_len) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (n_spheres < 0 || n_planes < 0 || n_triangles < 0 || accel_len < 0 || lights_len < 0 || lights_len % 6 != 0)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "negative count or lights_len not a multiple of 6");
+    if ((n_spheres && !spheres) || (n_planes && !planes) || (n_triangles && !triangles) || (accel_len && !accel) ||
+        (lights_len && !lights))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
+    ctx->has_scene = false;
+
+    // everything decided on the host (rt_scene_prep.h): validation, cull preconditions, both trees
+    rtp::Prepared prep;
+    std::string err;
+    rtp::Options opt;
+    opt.build_tight = ctx->build_tight, opt.tight_min_nodes = ctx->wf_min_nodes;
+    int rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
+                          accel_len, opt, &prep, &err);
+    if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
+    {  // the tight nodes follow the leaf tree's in one array: inner refs become indices of that array
+        const uint32_t base = (uint32_t)prep.bvh.nodes.size();
+        for (rtb::Node& nd : prep.tight.nodes) {
+            if (!(nd.ref0 & rtb::LEAF)) nd.ref0 += base;
+            if (!(nd.ref1 & rtb::LEAF)) nd.ref1 += base;
+        }
+    }
+    if (ctx->multi) return multi_upload(ctx, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
+    return upload_prepared(ctx, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
 }
 
 int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_triangles, rt_scene_info* info,
@@ -856,6 +876,7 @@ int rt_render_frames_device(rt_ctx* ctx, const float* cameras, int n_frames, int
 int rt_render(rt_ctx* ctx, const float camera[14], int max_bounces, float* rgb, uint8_t* rgba8,
               int32_t* primary_id, int32_t* final_id, rt_stats* stats) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (ctx->multi) return multi_render(ctx, camera, max_bounces, rgb, rgba8, primary_id, final_id, stats);
     int w, h;
     if (camera_size(camera, &w, &h) != RT_OK)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "camera[12..13] must hold an integral width/height in 1..65536");
@@ -959,3 +980,5 @@ int rt_eval_triangle(rt_ctx* ctx, int n, const float* o3, const float* d3, const
 }
 
 }  // extern "C"
+
+#include "rt_multi.h"

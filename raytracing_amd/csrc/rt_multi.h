@@ -1,0 +1,296 @@
+// rt_multi.h -- one context over several GPUs of a node (rt_create_multi, include/rt_mi355x.h).
+// Included by rt_mi355x.hip after the single-GPU render core; not a stand-alone header.
+//
+// the reference's host draws one frame per call on one GPU (RayTracer.cs:125-137).  Here one
+// call still returns one finished frame, but the frame is cut into 8-row bands dealt round-robin to the
+// context's devices (the scene is replicated: read-only, <= ~130 MB), every device renders its bands on its own
+// stream, and the bands are gathered on the first device over RCCL -- grouped ncclSend / ncclRecv, so each
+// peer's bands travel that peer's own xGMI link to the root -- where the un-permute kernel restores scanline
+// order.  Single process, single host thread, ncclCommInitAll.
+//
+// RCCL is loaded with dlopen when the first multi-GPU context is created: single-GPU users of the library
+// never load it, and a host process that already holds an RCCL (PyTorch ships its own) is not handed a second
+// copy through the link line.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) {
+            error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?");
+            return false;
+        }
+        auto sym = [&](const char* n) {
+            void* p = dlsym(lib, n);
+            if (!p) error = std::string("librccl.so lacks ") + n;
+            return p;
+        };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
+            dlclose(lib);
+            lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;  // process-wide; contexts are created from one host thread at a time (rt_mi355x.h)
+
+constexpr int MULTI_BAND_ROWS = 8;  // one row of 8x8-pixel tiles per band: finest interleave of sky / mesh / floor rows
+
+}  // namespace
+
+// Per-device state of a multi-GPU context.  sub[0] is the owning context itself (the root: frames are assembled
+// on its device); sub[1..] are ordinary single-GPU contexts of the other devices.
+struct rt_multi {
+    int n = 0;
+    std::vector<rt_ctx*> sub;
+    std::vector<hipStream_t> stream;
+    std::vector<ncclComm_t> comm;  // empty when the exchange does not go over RCCL (see use_rccl)
+    // device ids all different -> RCCL.  A list that names one device more than once cannot form a communicator
+    // ("duplicate GPU"); it is accepted so that every rank can be played on one GPU (tests), and its bands then move
+    // with device-to-device copies in stream order.  Everything else -- partition, launches, assembly -- is the same.
+    bool use_rccl = false;
+    struct Planes {
+        DevBuf rgb, rgba8, pid, fid, stats;
+    };
+    std::vector<Planes> local;  // each device's own bands: rt_padded_rows() x W pixels per plane
+    DevBuf gathered;            // root: [n][padded rows][W] elements of the plane being assembled
+    std::vector<hipEvent_t> done;  // copy path: device d's render has finished
+};
+
+namespace {
+
+int nccl_fail(rt_ctx* ctx, ncclResult_t r, const char* what) {
+    return fail(ctx, RT_ERR_DEVICE, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+}
+#define NCCL_TRY(ctx, expr)                                       \
+    do {                                                          \
+        ncclResult_t r_ = (expr);                                 \
+        if (r_ != ncclSuccess) return nccl_fail(ctx, r_, #expr);  \
+    } while (0)
+
+}  // namespace
+
+static void multi_release(rt_ctx* root) {
+    rt_multi* m = root->multi;
+    if (!m) return;
+    for (int d = 0; d < (int)m->sub.size(); d++) {
+        rt_ctx* c = m->sub[d];
+        if (!c) continue;
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        if (d < (int)m->comm.size() && m->comm[d]) (void)g_rccl.CommDestroy(m->comm[d]);
+        if (d < (int)m->local.size()) {
+            release(m->local[d].rgb), release(m->local[d].rgba8), release(m->local[d].pid), release(m->local[d].fid);
+            release(m->local[d].stats);
+        }
+        if (d < (int)m->done.size() && m->done[d]) (void)hipEventDestroy(m->done[d]);
+        if (d < (int)m->stream.size() && m->stream[d]) (void)hipStreamDestroy(m->stream[d]);
+    }
+    (void)hipSetDevice(root->device);
+    release(m->gathered);
+    for (int d = 1; d < (int)m->sub.size(); d++)
+        if (m->sub[d]) rt_destroy(m->sub[d]);
+    root->multi = nullptr;
+    delete m;
+}
+
+static int multi_upload(rt_ctx* root, const rtp::Prepared& prep, const void* spheres, int n_spheres, const void* planes, int n_planes,
+                        const void* triangles, int n_triangles, const float* lights, int lights_len) {
+    rt_multi* m = root->multi;
+    for (int d = 0; d < m->n; d++) {
+        rt_ctx* c = m->sub[d];
+        c->build_tight = root->build_tight, c->wf_min_nodes = root->wf_min_nodes;
+        const int rc = upload_prepared(c, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
+        if (rc != RT_OK) {
+            if (c != root) root->error = "device " + std::to_string(c->device) + ": " + c->error;
+            root->has_scene = false;
+            return rc;
+        }
+    }
+    return RT_OK;
+}
+
+// One plane's bands from every device to the root, then scanline order into `out` (a root device buffer).
+static int multi_gather_plane(rt_ctx* root, size_t elem, int w, int h, const std::vector<void*>& src, void* out) {
+    rt_multi* m = root->multi;
+    const int padded = rt_padded_rows(h, MULTI_BAND_ROWS, m->n);
+    const size_t chunk = (size_t)padded * w * elem;
+    HIP_TRY(root, hipSetDevice(root->device));
+    int rc = ensure(root, m->gathered, chunk * m->n);
+    if (rc != RT_OK) return rc;
+    unsigned char* g = (unsigned char*)m->gathered.p;
+    if (m->use_rccl) {
+        // grouped: every device sends its chunk to rank 0, rank 0 receives n chunks (its own included: a
+        // send to self inside a group is a local copy), all progressing concurrently on their own links
+        NCCL_TRY(root, g_rccl.GroupStart());
+        for (int d = 0; d < m->n; d++) {
+            NCCL_TRY(root, g_rccl.Send(src[d], chunk, ncclUint8, 0, m->comm[d], m->stream[d]));
+            NCCL_TRY(root, g_rccl.Recv(g + chunk * d, chunk, ncclUint8, d, m->comm[0], m->stream[0]));
+        }
+        NCCL_TRY(root, g_rccl.GroupEnd());
+    } else {
+        for (int d = 0; d < m->n; d++) {
+            HIP_TRY(root, hipStreamWaitEvent(m->stream[0], m->done[d], 0));
+            HIP_TRY(root, hipMemcpyAsync(g + chunk * d, src[d], chunk, hipMemcpyDeviceToDevice, m->stream[0]));
+        }
+    }
+    return rt_unpermute_bands(root, g, out, (int)elem, w, h, MULTI_BAND_ROWS, m->n, m->stream[0]);
+}
+
+// rt_render on a multi-GPU context.
+static int multi_render(rt_ctx* root, const float* camera, int max_bounces, float* rgb, uint8_t* rgba8, int32_t* primary_id,
+                        int32_t* final_id, rt_stats* stats) {
+    rt_multi* m = root->multi;
+    int w, h;
+    if (camera_size(camera, &w, &h) != RT_OK)
+        return fail(root, RT_ERR_INVALID_ARGUMENT, "camera[12..13] must hold an integral width/height in 1..65536");
+    if (!root->has_scene) return fail(root, RT_ERR_NO_SCENE, "rt_upload_scene has not succeeded on this context");
+    const int padded = rt_padded_rows(h, MULTI_BAND_ROWS, m->n);
+    const size_t lpx = (size_t)padded * w, px = (size_t)w * h;
+    int rc;
+    // every device renders its bands into its own compact planes, on its own stream
+    for (int d = 0; d < m->n; d++) {
+        rt_ctx* c = m->sub[d];
+        rt_multi::Planes& L = m->local[d];
+        HIP_TRY(root, hipSetDevice(c->device));
+        if ((rgb && (rc = ensure(c, L.rgb, lpx * 12))) || (rgba8 && (rc = ensure(c, L.rgba8, lpx * 4))) ||
+            (primary_id && (rc = ensure(c, L.pid, lpx * 4))) || (final_id && (rc = ensure(c, L.fid, lpx * 4))) ||
+            (stats && (rc = ensure(c, L.stats, sizeof(rt_stats))))) {
+            root->error = c->error;
+            return rc;
+        }
+        if (stats) HIP_TRY(root, hipMemsetAsync(L.stats.p, 0, sizeof(rt_stats), m->stream[d]));
+        c->traversal = root->traversal, c->supertile = root->supertile, c->allow_lds = false;
+        rc = rt_render_device(c, camera, max_bounces, stats ? RT_RENDER_REFERENCE_ORDER : RT_RENDER_DEFAULT, MULTI_BAND_ROWS, d,
+                              m->n, rgb ? (float*)L.rgb.p : nullptr, rgba8 ? (uint8_t*)L.rgba8.p : nullptr,
+                              primary_id ? (int32_t*)L.pid.p : nullptr, final_id ? (int32_t*)L.fid.p : nullptr, nullptr,
+                              stats ? (rt_stats*)L.stats.p : nullptr, m->stream[d]);
+        if (rc != RT_OK) {
+            if (c != root) root->error = "device " + std::to_string(c->device) + ": " + c->error;
+            return rc;
+        }
+        if (!m->use_rccl) HIP_TRY(root, hipEventRecord(m->done[d], m->stream[d]));
+    }
+    // gather + assemble each requested plane on the root, then hand it to the host
+    HIP_TRY(root, hipSetDevice(root->device));
+    if ((rgb && (rc = ensure(root, root->fb_rgb, px * 12))) || (rgba8 && (rc = ensure(root, root->fb_rgba8, px * 4))) ||
+        (primary_id && (rc = ensure(root, root->fb_pid, px * 4))) || (final_id && (rc = ensure(root, root->fb_fid, px * 4))))
+        return rc;
+    struct Job {
+        bool want;
+        size_t elem;
+        DevBuf rt_multi::Planes::*plane;
+        DevBuf* fb;
+        void* host;
+    } jobs[] = {{rgb != nullptr, 12, &rt_multi::Planes::rgb, &root->fb_rgb, rgb},
+                {rgba8 != nullptr, 4, &rt_multi::Planes::rgba8, &root->fb_rgba8, rgba8},
+                {primary_id != nullptr, 4, &rt_multi::Planes::pid, &root->fb_pid, primary_id},
+                {final_id != nullptr, 4, &rt_multi::Planes::fid, &root->fb_fid, final_id}};
+    for (const Job& j : jobs) {
+        if (!j.want) continue;
+        std::vector<void*> src(m->n);
+        for (int d = 0; d < m->n; d++) src[d] = (m->local[d].*(j.plane)).p;
+        if ((rc = multi_gather_plane(root, j.elem, w, h, src, j.fb->p)) != RT_OK) return rc;
+        HIP_TRY(root, hipSetDevice(root->device));
+        HIP_TRY(root, hipMemcpyAsync(j.host, j.fb->p, px * j.elem, hipMemcpyDeviceToHost, m->stream[0]));
+    }
+    if (stats) {  // every device counted its own bands: the frame's counters are their sum
+        std::memset(stats, 0, sizeof *stats);
+        for (int d = 0; d < m->n; d++) {
+            rt_stats part;
+            HIP_TRY(root, hipSetDevice(m->sub[d]->device));
+            HIP_TRY(root, hipStreamSynchronize(m->stream[d]));
+            HIP_TRY(root, hipMemcpy(&part, m->local[d].stats.p, sizeof part, hipMemcpyDeviceToHost));
+            const uint64_t* s = (const uint64_t*)&part;
+            uint64_t* t = (uint64_t*)stats;
+            for (size_t k = 0; k < sizeof(rt_stats) / 8; k++) t[k] += s[k];
+        }
+    }
+    for (int d = 0; d < m->n; d++) {  // the call returns a finished frame (and idle devices), like the reference's draw
+        HIP_TRY(root, hipSetDevice(m->sub[d]->device));
+        HIP_TRY(root, hipStreamSynchronize(m->stream[d]));
+    }
+    HIP_TRY(root, hipSetDevice(root->device));
+    return RT_OK;
+}
+
+extern "C" int rt_create_multi(const int* device_ids, int n_devices, rt_ctx** out) {
+    if (!out) return RT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) return RT_ERR_INVALID_ARGUMENT;
+    rt_ctx* root = nullptr;
+    int rc = rt_create(device_ids[0], &root);
+    if (rc != RT_OK) return rc;
+    rt_multi* m = new rt_multi();
+    root->multi = m;
+    m->n = n_devices;
+    m->sub.assign(n_devices, nullptr), m->stream.assign(n_devices, nullptr), m->done.assign(n_devices, nullptr);
+    m->local.resize(n_devices);
+    m->sub[0] = root;
+    bool distinct = true;
+    for (int d = 0; d < n_devices; d++)
+        for (int e = 0; e < d; e++) distinct &= device_ids[d] != device_ids[e];
+    m->use_rccl = distinct;
+    for (int d = 0; d < n_devices && rc == RT_OK; d++) {
+        if (d > 0) rc = rt_create(device_ids[d], &m->sub[d]);
+        if (rc != RT_OK) break;
+        if (hipSetDevice(device_ids[d]) != hipSuccess ||
+            hipStreamCreateWithFlags(&m->stream[d], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&m->done[d], hipEventDisableTiming) != hipSuccess)
+            rc = RT_ERR_DEVICE;
+    }
+    if (rc == RT_OK && m->use_rccl) {
+        if (!g_rccl.load()) {
+            rc = RT_ERR_DEVICE;
+            std::fprintf(stderr, "rt_create_multi: %s\n", g_rccl.error.c_str());
+        } else {
+            m->comm.assign(n_devices, nullptr);
+            const ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), n_devices, device_ids);
+            if (r != ncclSuccess) {
+                std::fprintf(stderr, "rt_create_multi: ncclCommInitAll: %s\n", g_rccl.GetErrorString(r));
+                m->comm.clear();
+                rc = RT_ERR_DEVICE;
+            }
+        }
+    }
+    if (rc != RT_OK) {
+        multi_release(root);
+        rt_destroy(root);
+        return rc;
+    }
+    (void)hipSetDevice(root->device);
+    *out = root;
+    return RT_OK;
+}
+
+extern "C" int rt_multi_info(const rt_ctx* ctx, int* n_devices, int* uses_rccl) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (n_devices) *n_devices = ctx->multi ? ctx->multi->n : 1;
+    if (uses_rccl) *uses_rccl = ctx->multi && ctx->multi->use_rccl ? 1 : 0;
+    return RT_OK;
+}

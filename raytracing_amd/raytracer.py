@@ -53,12 +53,22 @@ def check_scene(scene, tight_min_nodes=1000):
 
 class RayTracer:
     def __init__(self, device_id=0):
+        """device_id: a HIP device ordinal (rt_create), or a list of them (rt_create_multi: one context over
+        several GPUs, frames assembled on the first; RenderGL is then the multi-GPU render)."""
         self._lib = N.device_lib()
         self._ctx = C.c_void_p()
-        rc = self._lib.rt_create(int(device_id), C.byref(self._ctx))
-        if rc != 0:
-            self._ctx = C.c_void_p()
-            raise RtError(rc, f"rt_create(device {device_id}) failed (no MI355X visible?)")
+        if isinstance(device_id, (list, tuple)):
+            ids = (C.c_int * len(device_id))(*[int(d) for d in device_id])
+            rc = self._lib.rt_create_multi(ids, len(device_id), C.byref(self._ctx))
+            if rc != 0:
+                self._ctx = C.c_void_p()
+                raise RtError(rc, f"rt_create_multi(devices {list(device_id)}) failed")
+            device_id = device_id[0]
+        else:
+            rc = self._lib.rt_create(int(device_id), C.byref(self._ctx))
+            if rc != 0:
+                self._ctx = C.c_void_p()
+                raise RtError(rc, f"rt_create(device {device_id}) failed (no MI355X visible?)")
         self.device_id = int(device_id)
         self.cameraData = None
         self.scene = None
@@ -202,6 +212,11 @@ class RayTracer:
 
     def padded_rows(self, height, band_rows, world):
         return self._lib.rt_padded_rows(height, band_rows, world)
+
+    def multi_info(self):
+        n, r = C.c_int(), C.c_int()
+        self._check(self._lib.rt_multi_info(self._ctx, C.byref(n), C.byref(r)))
+        return {"n_devices": n.value, "uses_rccl": bool(r.value)}
 
     def scene_info(self):
         info = N.rt_scene_info()

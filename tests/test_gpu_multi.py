@@ -1,0 +1,55 @@
+"""GPU: rt_create_multi -- one context over several GPUs behind the C ABI.  The one-GPU box
+drives it (a) with n = 1, the real RCCL path (ncclCommInitAll, grouped ncclSend/ncclRecv to the root), and
+(b) with the same device named three times, which plays three ranks on the one GPU (bands move with
+device-to-device copies, everything else is the multi-GPU code path).  Either way rt_render must return
+the single-GPU frame, and the reference-rule counters summed over the devices must equal the oracle's."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import assert_frame_matches, assert_stats_match, oracle_render
+from raytracing_amd import RayTracer
+from raytracing_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("devices,rccl", [([0], True), ([0, 0, 0], False)], ids=["n1-rccl", "n3-on-one-gpu"])
+@pytest.mark.parametrize("name,params,depth,size", [("TestScene1", None, 10, (333, 190)), ("Soup", [8000, 80, 8], 4, (160, 90))])
+def test_multi_context_renders_the_single_gpu_frame(devices, rccl, name, params, depth, size, rt, scene_of):
+    sc = scene_of(name, params)
+    cam = sc.camera_for(*size)
+    rt.SendPrimitivesToShader(sc)
+    rt.PrepareRenderOpenGL(cam)
+    single = rt.RenderGL(depth)
+    with RayTracer(devices) as m:
+        assert m.multi_info() == {"n_devices": len(devices), "uses_rccl": rccl}
+        m.SendPrimitivesToShader(sc)
+        m.PrepareRenderOpenGL(cam)
+        for _ in range(2):                      # twice: buffers are reused, streams stay ordered
+            out = m.RenderGL(depth)
+            for k in ("rgb", "rgba8", "primary_id", "final_id"):
+                assert np.array_equal(out[k].view(np.uint8), single[k].view(np.uint8)), f"{name} {k}"
+        slow = m.RenderGL(depth, stats=True)    # reference-order kernel on every device, counters summed
+        ref = oracle_render(sc, cam, depth, threads=16)
+        assert_frame_matches(slow, ref, f"{name} multi reference-order")
+        assert_stats_match(slow["stats"], ref["counters"], f"{name} multi")
+        if name == "Soup":                      # the staged pipeline on every device
+            m.set_option(m.OPTION_TRAVERSAL, m.TRAVERSAL_WAVEFRONT)
+            out = m.RenderGL(depth)
+            assert np.array_equal(out["rgb"].view(np.uint8), single["rgb"].view(np.uint8))
+            assert np.array_equal(out["final_id"], single["final_id"])
+
+
+def test_multi_context_argument_errors():
+    lib = N.device_lib()
+    ctx = C.c_void_p()
+    assert lib.rt_create_multi(None, 1, C.byref(ctx)) == -1 and not ctx
+    ids = (C.c_int * 2)(0, 0)
+    assert lib.rt_create_multi(ids, 0, C.byref(ctx)) == -1 and not ctx
+    bad = (C.c_int * 2)(0, 9999)
+    assert lib.rt_create_multi(bad, 2, C.byref(ctx)) == -4 and not ctx     # RT_ERR_DEVICE: no such GPU
+    n, r = C.c_int(), C.c_int()
+    with RayTracer(0) as one:
+        assert one.multi_info() == {"n_devices": 1, "uses_rccl": False}
