@@ -98,15 +98,25 @@ enum {
     RT_OPTION_SUPERTILE = 2, /* edge, in 8x8-pixel tiles, of the super-tiles dealt round-robin to the
                                 XCDs by the global-memory kernels (default 2, 1..64) */
     RT_OPTION_TRAVERSAL = 3, /* RT_TRAVERSAL_*: which fast kernel renders (default AUTO: by scene size) */
-    RT_OPTION_TIGHT_TREE = 4, /* 1 (default): uploads of large scenes also build a per-primitive tree that the
-                                staged pipeline walks as a filter in front of the reference's leaf-box rule
-                                (64 B per primitive, ~0.25 s of host time per million); 0: neither built nor used */
-    RT_OPTION_WAVEFRONT_MIN_NODES = 5 /* scenes with at least this many flattened node records (default 1000) get the
-                                tight tree at upload and are candidates for RT_TRAVERSAL_WAVEFRONT under AUTO: the
-                                first render of a (scene, frame size, bounces) is timed with the megakernel, the
-                                second with the staged pipeline, later ones use the faster (size alone does not
-                                tell a triangle soup from a field of meshes); from 100000 nodes on AUTO takes the
-                                staged pipeline without asking */
+    RT_OPTION_TIGHT_TREE = 4, /* 1 (default): uploads of scenes with at least RT_OPTION_TIGHT_MIN_NODES node records
+                                whose primitives were verified to sit inside their leaf boxes also build a
+                                per-primitive tree that the staged pipeline walks with a cheap conservative box
+                                test, as a filter in front of the reference's leaf-box rule (64 B per primitive,
+                                ~0.25 s of host time per million); 0: neither built nor used */
+    RT_OPTION_WAVEFRONT_MIN_NODES = 5, /* scenes with at least this many flattened node records (default 1000) are
+                                candidates for RT_TRAVERSAL_WAVEFRONT under AUTO: the first two renders of a (scene,
+                                frame size, bounces) use the megakernel, the next two the staged pipeline (the second
+                                of each pair is timed), later ones use the faster (size alone does not tell a triangle
+                                soup from a field of meshes); from 100000 nodes on AUTO takes the staged pipeline
+                                without asking */
+    RT_OPTION_TIGHT_MIN_NODES = 6, /* scenes with fewer flattened node records get no tight tree (default 1000; only
+                                the staged pipeline walks it -- in the megakernel it measured slower) */
+    RT_OPTION_COOP_SHADOWS = 7 /* 1: the BVH megakernel keeps the lanes of a wave in step through the mirror loop and,
+                                in bounces where fewer than 40 lanes need shadow rays, regroups those rays over all
+                                64 lanes (ballot compaction into an LDS queue), so pixels that are still bouncing use
+                                the lanes of those that have finished; 0 (default): every pixel traces its own shadow
+                                rays one after the other.  Measured: scenes whose long waves are sparse gain 10 %
+                                (TestScene1), others lose 5 % (lock-step + 2 more VGPRs) */
 };
 enum {
     RT_TRAVERSAL_AUTO = 0,

@@ -276,8 +276,13 @@ inline void build(const rtf::Flat& flat, Bvh* out) {
 //             the closest approach) by <= sqrt(68 eps)/2 |o-c|, and the closest approach misses the
 //             sphere by at most the same amount: X_c is within 2.0e-3 |o-c| <= 3.5e-3 E of the
 //             sphere.  The box is c +- (r + pad_sphere), pad_sphere = 2^-8 E_build = 3.9e-3 E_build.
-//   unbounded triangles (rtf::meta_nocull: the reference accepts them on a whole line or plane) get
-//             a box no ray misses and hang in the spheres' tree.
+//   unbounded triangles (rtf::meta_nocull: the reference accepts them on a whole line or plane, wherever
+//             the ray's LINE passes their leaf box -- the box test has no distance bound) get that
+//             reference leaf box grown by pad_tri, hang in the spheres' tree, and carry the never-cull
+//             mark (kind 3, propagated upwards): SlabHit drops its distance window for them.  If the exact
+//             test accepts the leaf box, its three computed slab intervals share a point t*; the padded
+//             box's intervals, as SlabHit computes them, contain every computed interval of the unpadded box
+//             (pad_tri |1/d_k| >> the rounding of either formula), hence t*: the filter passes.
 //   slab test errors (fma form, 1/d rounded) are < 6 eps E in space: covered by either pad.
 //
 // E_build is fixed at build time, so only rays with E(o) = max_k(|o_k| + extent_k) <= E_build and a
@@ -320,9 +325,12 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
             it.ref = LEAF | ((uint32_t)kind << 29) | (1u << 24) | (uint32_t)slot;
             double lo[3], hi[3], pad;
             if (kind == rtf::KIND_TRI && in.tri_unbounded && (*in.tri_unbounded)[slot]) {
-                // hits anywhere along a line or plane: a box no ray misses; kept out of the triangles' tree
+                // hits anywhere along a line or plane -- but only where the ray's LINE passes the reference leaf
+                // box (the exact rule): that box grown by the triangles' pad, walked without a distance window
+                // (kind 3 = never cull, propagated to the inner refs above).  Kept out of the triangles' tree.
                 (*tri_slot_leaf)[slot] = (int32_t)ni;
-                for (int c = 0; c < 3; c++) it.lo[c] = -3.402823466e+38f, it.hi[c] = 3.402823466e+38f;
+                const float flo[3] = {fn.minx, fn.miny, fn.minz}, fhi[3] = {fn.maxx, fn.maxy, fn.maxz};
+                for (int c = 0; c < 3; c++) it.lo[c] = down((double)flo[c] - in.pad_tri), it.hi[c] = up((double)fhi[c] + in.pad_tri);
                 it.ref = LEAF | ((uint32_t)rtf::KIND_TRI_UNBOUNDED << 29) | (1u << 24) | (uint32_t)slot;
                 sphere_items.push_back(it);
                 continue;

@@ -248,14 +248,17 @@ __device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4
 // < 6 eps E in space), never rejects a box whose primitive's test can accept a t in [t_lo, t_hi];
 // exactness is restored by the leaf-box check on accepted hits (rt_wavefront.h).  Requires
 // make_tight_ray; finite everywhere for |1/d| <= 1e30 and coordinates <= 4e6.
-__device__ __forceinline__ bool SlabHit(const BoxRay& r, float4 lo, float4 hi, float t_lo, float t_hi, float* entry) {
+// nocull: an unbounded triangle lies below (rtb::ref_nocull): the reference accepts it wherever the ray's LINE
+// passes its leaf box, so only the line test applies, not the distance window.
+__device__ __forceinline__ bool SlabHit(const BoxRay& r, float4 lo, float4 hi, float t_lo, float t_hi, float* entry,
+                                        bool nocull = false) {
     const float x0 = __builtin_fmaf(lo.x, r.inv.x, r.padinv.x), x1 = __builtin_fmaf(hi.x, r.inv.x, r.padinv.x);
     const float y0 = __builtin_fmaf(lo.y, r.inv.y, r.padinv.y), y1 = __builtin_fmaf(hi.y, r.inv.y, r.padinv.y);
     const float z0 = __builtin_fmaf(lo.z, r.inv.z, r.padinv.z), z1 = __builtin_fmaf(hi.z, r.inv.z, r.padinv.z);
     const float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
     const float ef = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
     *entry = en;
-    return (en <= ef) & (en <= t_hi) & (ef >= t_lo);
+    return (en <= ef) & (((en <= t_hi) & (ef >= t_lo)) | nocull);
 }
 // May this ray walk the tight tree?  (E_build covers its origin, 1/d small enough that no slab
 // product overflows.)  If so the ray's padinv is replaced by -o*inv.

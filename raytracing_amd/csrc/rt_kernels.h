@@ -177,19 +177,28 @@ __device__ __forceinline__ void bvh_walk(const G& g, const BoxRay& br, bool aliv
 // ------------------------------------------------------------------------------------------
 // FindClosestIntersection, raytracer_fs.glsl:241-297
 // ------------------------------------------------------------------------------------------
+// alive = false (fast kernels only): the lane has no ray (cooperative kernels keep every lane of the wave in
+// step); it tests nothing and returns "no hit".
 template <bool REF, class G>
 __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V3 o, V3 d, float minDistance,
-                                                uint32_t* cnt) {
+                                                uint32_t* cnt, bool alive = true) {
     Closest h = fresh_closest();
     const BoxRay br = REF ? make_box_ray(o, d)
                           : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
+    // fast kernels: distance only per test; the normal IntersectSphere forms at the accepted t
+    // (raytracer_fs.glsl:106-111) is computed once for the winner, after the walk (same expression, same bits)
     auto sphere = [&](int slot) {
         const float4 s = g.sphere(slot);
-        if (REF) cnt[C_SPHERE]++;
-        const float4 r = IntersectSphere(o, d, v3(s.x, s.y, s.z), s.w);
-        if (closer(r.w, 0, slot, minDistance, h)) {
-            if (REF) cnt[C_MAT]++;
-            h.t = r.w, h.kind = 0, h.index = slot, h.n = v3(r.x, r.y, r.z);
+        if (REF) {
+            cnt[C_SPHERE]++;
+            const float4 r = IntersectSphere(o, d, v3(s.x, s.y, s.z), s.w);
+            if (closer(r.w, 0, slot, minDistance, h)) {
+                cnt[C_MAT]++;
+                h.t = r.w, h.kind = 0, h.index = slot, h.n = v3(r.x, r.y, r.z);
+            }
+        } else {
+            const float t = IntersectSphereT(o, d, v3(s.x, s.y, s.z), s.w);
+            if (closer(t, 0, slot, minDistance, h)) h.t = t, h.kind = 0, h.index = slot;
         }
         return false;
     };
@@ -220,7 +229,7 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
         planes();
         walk<true>(g, S.n_nodes, br, 2, false, cnt, sphere, tri);
     } else {
-        planes();
+        if (alive) planes();
         // edge tests only for a t the acceptance rule below could still take
         auto tri_fast = [&](int slot) {
             const TriG tg = load_tri(g, slot);
@@ -230,17 +239,21 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
         };
         if constexpr (is_bvh<G>::value) {
             const bool regular = ray_is_regular(br);
-            if (!regular) {  // zero direction component etc.: the exact tree, exhaustively (rare)
+            if (!regular && alive) {  // zero direction component etc.: the exact tree, exhaustively (rare)
                 auto tri_b = [&](int slot) {
                     tri_fast(slot);
                     return false;
                 };
                 walk<false>(g, S.n_nodes, br, 3, false, nullptr, sphere, tri_b);
             }
-            bvh_walk(g, br, regular, minDistance, [&] { return h.t; }, sphere, tri_fast, [] { return false; });
+            bvh_walk(g, br, regular && alive, minDistance, [&] { return h.t; }, sphere, tri_fast, [] { return false; });
         } else {
-            wave_walk(g, S.n_nodes, br, true, minDistance, [&] { return h.t; }, sphere, tri_fast,
+            wave_walk(g, S.n_nodes, br, alive, minDistance, [&] { return h.t; }, sphere, tri_fast,
                       [] { return false; });
+        }
+        if (h.kind == 0) {
+            const float4 s = g.sphere(h.index);
+            h.n = normalize((o + h.t * d) - v3(s.x, s.y, s.z));
         }
     }
     return h;
@@ -249,9 +262,10 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
 // ------------------------------------------------------------------------------------------
 // ObjectInWayOfLight, raytracer_fs.glsl:200-240
 // ------------------------------------------------------------------------------------------
+// alive = false (fast kernels only): the lane has no ray; nothing is tested, the result is meaningless.
 template <bool REF, class G>
 __device__ __forceinline__ bool object_in_way(const DevScene& S, const G& g, float distanceToLight, V3 o, V3 d,
-                                              uint32_t* cnt) {
+                                              uint32_t* cnt, bool alive = true) {
     const BoxRay br = REF ? make_box_ray(o, d)
                           : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
     bool blocked = false;
@@ -289,8 +303,8 @@ __device__ __forceinline__ bool object_in_way(const DevScene& S, const G& g, flo
         return blocked;
     } else {
         // any-hit is order independent: cheapest test first, leave at the first blocker
-        // (a lane that is already blocked sits the rest of the walk out)
-        blocked = plane_blocks();
+        // (a lane that is already blocked sits the rest of the walk out; so does a lane without a ray)
+        blocked = alive ? plane_blocks() : true;
         auto sphere = [&](int slot) {
             if (blocked) return;
             const float4 s = g.sphere(slot);
@@ -475,6 +489,160 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
         if (REF && zero) cnt[C_ZERO_TERM]++;
         if (!REF && zero) return true;
         return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt);
+    });
+    out.rgb = finalColor + combined * mult;
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------
+// Cooperative shadow rays (per-lane BVH megakernel).
+//
+// shade_pixel traces the L shadow rays of a shaded point one after the other in the pixel's own lane.  In a
+// scene with mirrors the lanes of a wave leave the bounce loop at different times, and the wave then runs a
+// long chain of dependent traversals -- (1 bounce ray + L shadow rays) per bounce -- for the few pixels that
+// are still bouncing, with most of its lanes idle (TestScene1: a dozen waves finish a 430 us chain of 70
+// traversals per lane, 250 us after every other wave has ended).  Here the wave keeps all its lanes in step
+// and regroups the shadow rays of the pixels that need any:
+//   * every pixel lane decides per light whether a ray is needed (the exact-zero light term test) and appends
+//     (pixel lane, light) to a queue in LDS -- ballot + mbcnt compaction, light-major, so that the rays traced
+//     side by side go to one light from neighbouring points;
+//   * all 64 lanes then trace 64 queue entries at a time, whoever's pixel they belong to (the hit point comes
+//     from LDS, the light ray is formed from it by the expressions shade_pixel uses: same bits), and OR the
+//     result into the pixel's mask word in LDS;
+//   * every pixel lane shades from its mask, lights in index order, as before.
+// With k pixels alive the shadow phase of a bounce takes ceil(k L' / 64) traversal rounds (L' = lights not
+// ruled out) instead of L.  Arithmetic per pixel is unchanged; so are the results.
+// LDS per wave: hit points 3 x 64 floats, 64 mask words, 64 x COOP_CH 16-bit queue entries.
+// ------------------------------------------------------------------------------------------
+constexpr int COOP_CH = 8;                          // lights per queue fill
+constexpr int COOP_DWORDS = 192 + 64 + 32 * COOP_CH;  // per wave, after the traversal stacks
+constexpr int COOP_MAX_LIGHTS = 32;                 // one mask word per pixel; scenes with more lights take shade_pixel
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // producer and consumer lanes belong to one wave: LDS operations of a wave complete in issue order, the
+    // fences only keep the compiler from moving accesses across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Bit l of the result = light l adds nothing at this point (blocked, or its term is an exact zero either way).
+// Every lane of the wave must call this together; wants = this lane shades a point now.
+template <class G>
+__device__ __forceinline__ uint32_t coop_shadows(const DevScene& S, const G& g, int coop_base, bool wants, V3 hitPos,
+                                                 const Surface& sf, bool mirror, V3 rayDirection) {
+    if (__ballot(wants) == 0ull) return 0u;
+    float* const hx = (float*)rt_lds + coop_base;
+    uint32_t* const mask = (uint32_t*)rt_lds + coop_base + 192;
+    unsigned short* const q = (unsigned short*)((uint32_t*)rt_lds + coop_base + 256);
+    const int lane = (int)__lane_id();
+    const int L = S.lights_len / 6;
+    hx[lane] = hitPos.x, hx[64 + lane] = hitPos.y, hx[128 + lane] = hitPos.z;
+    mask[lane] = 0u;
+    uint32_t own = 0u;
+    for (int l0 = 0; l0 < L; l0 += COOP_CH) {
+        const int l1 = l0 + COOP_CH < L ? l0 + COOP_CH : L;
+        int n = 0;  // wave-uniform
+        for (int l = l0; l < l1; l++) {
+            bool need = false;
+            if (wants) {
+                const LightRay lr = light_ray(S, l, hitPos);
+                if (light_term_is_zero(sf, mirror, rayDirection, lr))
+                    own |= 1u << l;
+                else
+                    need = true;
+            }
+            const unsigned long long m = __ballot(need);
+            if (need) q[n + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(lane | ((l - l0) << 6));
+            n += __popcll(m);
+        }
+        wave_lds_sync();
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool have = i < n;
+            V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
+            float dist = 0.0f;
+            int pl = 0, l = 0;
+            if (have) {
+                const int e = q[i];
+                pl = e & 63, l = l0 + (e >> 6);
+                o = v3(hx[pl], hx[64 + pl], hx[128 + pl]);
+                const LightRay lr = light_ray(S, l, o);
+                d = lr.L, dist = lr.dist;
+            }
+            const bool blocked = object_in_way<false>(S, g, dist, o, d, nullptr, have);
+            if (have && blocked) atomicOr(&mask[pl], 1u << l);
+        }
+        wave_lds_sync();
+    }
+    return own | mask[lane];
+}
+
+// shade_pixel for a whole wave: every lane of the wave must call this (live = the lane has a pixel).  Per pixel
+// the sequence of operations is shade_pixel's.  The mirror loop runs until no lane of the wave bounces any more;
+// in an iteration where fewer than COOP_DENSE lanes need shadow rays those rays are regrouped over the wave
+// (coop_shadows), otherwise every lane traces its own, one light after the other, as shade_pixel does (regrouping
+// 64 x L rays gains nothing and costs a second evaluation of each light ray).  The final Phong term is computed
+// by all lanes together after the loop, as in shade_pixel.
+#ifndef RT_COOP_DENSE
+#define RT_COOP_DENSE 40
+#endif
+template <class G>
+__device__ __forceinline__ PixelOut shade_pixel_coop(const DevScene& S, const G& g, int coop_base, const float* cam, float px,
+                                                     float py, int maxBounces, bool live) {
+    V3 rayOrigin = v3(cam[0], cam[1], cam[2]);
+    V3 rayDirection = live ? primary_direction(cam, px, py) : v3(0, 0, 0);
+    Closest h = find_closest<false>(S, g, rayOrigin, rayDirection, 0.0f, nullptr, live);
+    Surface sf = (h.kind != 3) ? resolve_surface(S, h) : no_surface();
+    PixelOut out;
+    out.primary_id = sf.id;
+    V3 mult = v3(1, 1, 1);
+    V3 finalColor = v3(0, 0, 0);
+    int bounces = 0;
+    for (;;) {
+        const bool mirror = live && sf.pure && bounces < maxBounces;
+        if (__ballot(mirror) == 0ull) break;
+        const bool lit = mirror && (sf.diffuse.x != 0 || sf.diffuse.y != 0 || sf.diffuse.z != 0);
+        const V3 hitPos = rayOrigin + h.t * rayDirection;
+        if (__popcll(__ballot(lit)) >= RT_COOP_DENSE) {
+            if (lit) {
+                const V3 combined = mirror_diffuse_term(S, sf, hitPos, [&](int, const LightRay& lr) {
+                    if (light_term_is_zero(sf, true, rayDirection, lr)) return true;
+                    return object_in_way<false>(S, g, lr.dist, hitPos, lr.L, nullptr);
+                });
+                finalColor = finalColor + combined * mult;
+            }
+        } else {
+            const uint32_t dark = coop_shadows(S, g, coop_base, lit, hitPos, sf, true, rayDirection);
+            if (lit)
+                finalColor = finalColor + mirror_diffuse_term(S, sf, hitPos, [&](int l, const LightRay&) {
+                                              return ((dark >> l) & 1u) != 0u;
+                                          }) * mult;
+        }
+        if (mirror) {
+            mult = mult * sf.specular;
+            const V3 refl = mirror_direction(sf, rayDirection);
+            rayOrigin = hitPos;
+            rayDirection = refl;
+        }
+        // the bounce rays of the lanes that go on (the others sit the walk out)
+        const Closest h2 = find_closest<false>(S, g, rayOrigin, rayDirection, RT_EPSILON, nullptr, mirror);
+        if (mirror) {
+            h = h2;
+            sf = (h.kind != 3) ? resolve_surface(S, h) : no_surface();
+            bounces++;
+        }
+    }
+    out.bounces = bounces;
+    out.final_id = sf.id;
+    if (!live || h.t == RT_FLT_BIG) {
+        out.rgb = finalColor + v3(0.5f, 0.6f, 1.0f) * mult;
+        return out;
+    }
+    const V3 hitPos = rayOrigin + h.t * rayDirection;
+    const V3 combined = phong_term(S, sf, hitPos, rayDirection, [&](int, const LightRay& lr) {
+        if (light_term_is_zero(sf, false, rayDirection, lr)) return true;
+        return object_in_way<false>(S, g, lr.dist, hitPos, lr.L, nullptr);
     });
     out.rgb = finalColor + combined * mult;
     return out;
@@ -666,10 +834,14 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 #ifndef RT_BVH_WAVES_PER_EU
 #define RT_BVH_WAVES_PER_EU 3
 #endif
-// UNB: see GeomBvhT.
-template <bool UNB>
-__global__ __launch_bounds__(64 * BLOCK_WAVES) __attribute__((amdgpu_waves_per_eu(RT_BVH_WAVES_PER_EU, 8))) void k_render_bvh(
-    const RenderArgs a) {
+// UNB: see GeomBvhT.  COOP: the shadow rays of a bounce are regrouped over the lanes of the wave (coop_shadows);
+// dynamic LDS then also holds COOP_DWORDS per wave behind the stacks.
+#ifndef RT_COOP_WAVES_PER_EU
+#define RT_COOP_WAVES_PER_EU 4
+#endif
+template <bool UNB, bool COOP>
+__global__ __launch_bounds__(64 * BLOCK_WAVES)
+    __attribute__((amdgpu_waves_per_eu(COOP ? RT_COOP_WAVES_PER_EU : RT_BVH_WAVES_PER_EU, 8))) void k_render_bvh(const RenderArgs a) {
     int tx, ty, block = blockIdx.x;
     float cam[14];
     PriorityRect prio;
@@ -689,7 +861,11 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) __attribute__((amdgpu_waves_per_e
 #ifdef RT_DIAG_WAVE_TIMES  // diagnostic build only: id planes receive each wave's start / end on the 100 MHz clock
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (live) {
+    if (COOP) {  // every lane takes part, with or without a pixel
+        const int coop_base = BLOCK_WAVES * 64 * a.scene.bvh_levels + wave * COOP_DWORDS;
+        const PixelOut p = shade_pixel_coop(a.scene, g, coop_base, cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, live);
+        if (live) store_pixel(a, frame, x, r, p);
+    } else if (live) {
         const PixelOut p =
             shade_pixel<false>(a.scene, g, cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, nullptr);
         store_pixel(a, frame, x, r, p);

@@ -61,7 +61,12 @@ struct rt_ctx {
     } tune;
     long long scene_serial = 0;
     bool prioritise = true;   // RT_PRIORITISE=0 (development): deal the tiles out in plain row-major order
+    bool coop_shadows = false;  // RT_OPTION_COOP_SHADOWS: the BVH megakernel regroups the shadow rays of sparse bounces over
+                                // the wave.  Off: TestScene1 720p d10 0.49 -> 0.44 ms, but teapot 4K 0.62 -> 0.66 ms and
+                                // TeapotTable 0.67 -> 0.71 ms
     bool build_tight = true;  // RT_OPTION_TIGHT_TREE (takes effect at the next upload and at once for renders)
+    int tight_min_nodes = 1000;  // RT_OPTION_TIGHT_MIN_NODES: scenes with fewer flat nodes get no tight tree (only the
+                                 // staged pipeline walks it: measured slower in the megakernel)
     int traversal = RT_TRAVERSAL_AUTO;  // RT_OPTION_TRAVERSAL
     int bvh_min_nodes = 0;              // auto: scenes with at least this many flat nodes take the BVH kernel
                                         // (measured faster than the wave walk on every scene)
@@ -315,6 +320,7 @@ int rt_create(int device_id, rt_ctx** out) {
     }
     if (const char* v = getenv("RT_PRIORITISE")) ctx->prioritise = atoi(v) != 0;
     if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development overrides
+    if (const char* v = getenv("RT_COOP")) ctx->coop_shadows = atoi(v) != 0;
     if (const char* v = getenv("RT_WF_MIN_NODES")) ctx->wf_min_nodes = std::max(0, atoi(v));
     if (const char* v = getenv("RT_TRAVERSAL")) {  // development override of RT_OPTION_TRAVERSAL
         const int t = atoi(v);
@@ -382,6 +388,13 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
             return RT_OK;
         case RT_OPTION_TIGHT_TREE:
             ctx->build_tight = value != 0;
+            return RT_OK;
+        case RT_OPTION_COOP_SHADOWS:
+            ctx->coop_shadows = value != 0;
+            return RT_OK;
+        case RT_OPTION_TIGHT_MIN_NODES:
+            if (value < 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "node threshold must be >= 0");
+            ctx->tight_min_nodes = value;
             return RT_OK;
         case RT_OPTION_SUPERTILE:
             if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "supertile must be 1..64");
@@ -530,7 +543,7 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     rtp::Prepared prep;
     std::string err;
     rtp::Options opt;
-    opt.build_tight = ctx->build_tight, opt.tight_min_nodes = ctx->wf_min_nodes;
+    opt.build_tight = ctx->build_tight, opt.tight_min_nodes = ctx->tight_min_nodes;
     int rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
                           accel_len, opt, &prep, &err);
     if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
@@ -803,10 +816,15 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
         if (rc != RT_OK) return rc;
         hipLaunchKernelGGL(k_render_bvh_lds, dim3(grid), dim3(LDS_BLOCK), ctx->lds_bytes, st, a);
         if ((rc = chain_end(ctx, st)) != RT_OK) return rc;
-    } else if (use_bvh)
-        hipLaunchKernelGGL(ctx->info.unbounded_triangles > 0 ? k_render_bvh<true> : k_render_bvh<false>,
-                           dim3(n_blocks * n_frames), dim3(64 * BLOCK_WAVES),
-                           (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4, st, a);
+    } else if (use_bvh) {
+        const bool unb = ctx->info.unbounded_triangles > 0;
+        const size_t stacks = (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4;
+        const bool coop = ctx->coop_shadows && a.scene.lights_len / 6 <= COOP_MAX_LIGHTS && a.scene.lights_len > 0;
+        void (*kern)(const RenderArgs) = coop ? (unb ? k_render_bvh<true, true> : k_render_bvh<false, true>)
+                                              : (unb ? k_render_bvh<true, false> : k_render_bvh<false, false>);
+        hipLaunchKernelGGL(kern, dim3(n_blocks * n_frames), dim3(64 * BLOCK_WAVES),
+                           stacks + (coop ? (size_t)BLOCK_WAVES * COOP_DWORDS * 4 : 0), st, a);
+    }
     else
         hipLaunchKernelGGL(k_render<false>, dim3(n_blocks * n_frames), dim3(64 * BLOCK_WAVES), 0, st, a);
     HIP_TRY(ctx, hipGetLastError());

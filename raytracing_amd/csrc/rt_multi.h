@@ -124,7 +124,7 @@ static int multi_upload(rt_ctx* root, const rtp::Prepared& prep, const void* sph
     rt_multi* m = root->multi;
     for (int d = 0; d < m->n; d++) {
         rt_ctx* c = m->sub[d];
-        c->build_tight = root->build_tight, c->wf_min_nodes = root->wf_min_nodes;
+        c->build_tight = root->build_tight, c->wf_min_nodes = root->wf_min_nodes, c->tight_min_nodes = root->tight_min_nodes;
         const int rc = upload_prepared(c, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
         if (rc != RT_OK) {
             if (c != root) root->error = "device " + std::to_string(c->device) + ": " + c->error;
@@ -185,7 +185,7 @@ static int multi_render(rt_ctx* root, const float* camera, int max_bounces, floa
             return rc;
         }
         if (stats) HIP_TRY(root, hipMemsetAsync(L.stats.p, 0, sizeof(rt_stats), m->stream[d]));
-        c->traversal = root->traversal, c->supertile = root->supertile, c->allow_lds = false;
+        c->traversal = root->traversal, c->supertile = root->supertile, c->allow_lds = false, c->coop_shadows = root->coop_shadows;
         rc = rt_render_device(c, camera, max_bounces, stats ? RT_RENDER_REFERENCE_ORDER : RT_RENDER_DEFAULT, MULTI_BAND_ROWS, d,
                               m->n, rgb ? (float*)L.rgb.p : nullptr, rgba8 ? (uint8_t*)L.rgba8.p : nullptr,
                               primary_id ? (int32_t*)L.pid.p : nullptr, final_id ? (int32_t*)L.fid.p : nullptr, nullptr,

@@ -17,7 +17,7 @@ namespace rtp {
 
 struct Options {
     bool build_tight = true;
-    int tight_min_nodes = 8000;  // flat node records from which a scene gets the tight tree
+    int tight_min_nodes = 1000;  // flat node records from which a scene gets the tight tree
 };
 
 struct Prepared {
@@ -184,8 +184,14 @@ inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, cons
                         return "sphere sticks out of its padded tight box";
             } else {
                 if (seen_tri[first]++) return "triangle slot reached twice";
-                if (tight_of->tri_unbounded[first]) {
-                    if (kind != rtf::KIND_TRI_UNBOUNDED || td.lo[0] > -3e38f || td.hi[0] < 3e38f) return "unbounded triangle in a finite box";
+                if (tight_of->tri_unbounded[first]) {  // its reference leaf box, grown by the pad, marked never-cull
+                    const rtf::FlatNode& fn = tight_of->flat.nodes[tight_of->tri_slot_leaf[first]];
+                    const float flo[3] = {fn.minx, fn.miny, fn.minz}, fhi[3] = {fn.maxx, fn.maxy, fn.maxz};
+                    if (kind != rtf::KIND_TRI_UNBOUNDED) return "unbounded triangle without the never-cull kind";
+                    for (int c = 0; c < 3; c++)
+                        if (!((double)flo[c] - tight_of->pad_tri >= td.lo[c] - 1e-6 * std::fabs(td.lo[c]) &&
+                              (double)fhi[c] + tight_of->pad_tri <= td.hi[c] + 1e-6 * std::fabs(td.hi[c])))
+                            return "unbounded triangle's box does not contain its padded reference leaf box";
                     continue;
                 }
                 const float* rec = (const float*)(triangles + (size_t)tight_of->flat.tri_slot_id[first] * 96);

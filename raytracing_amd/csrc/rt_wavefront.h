@@ -172,8 +172,8 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
                 const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
                 bool h0, h1;
                 if (job.tight) {  // conservative filter (rt_bvh.h build_tight)
-                    h0 = SlabHit(job.br, q0, q1, job.t_lo, th, &e0);
-                    h1 = SlabHit(job.br, q2, q3, job.t_lo, th, &e1);
+                    h0 = SlabHit(job.br, q0, q1, job.t_lo, th, &e0, G::unbounded && rtb::ref_nocull(r0));
+                    h1 = SlabHit(job.br, q2, q3, job.t_lo, th, &e1, G::unbounded && rtb::ref_nocull(r1));
                 } else {  // the reference's test on the reference's leaf boxes
                     h0 = IntersectBoundingBoxCull(job.br, q0, q1, job.t_lo, th, &e0, G::unbounded && rtb::ref_nocull(r0));
                     h1 = IntersectBoundingBoxCull(job.br, q2, q3, job.t_lo, th, &e1, G::unbounded && rtb::ref_nocull(r1));

@@ -83,7 +83,7 @@ def test_config5_teapottable_1080p_band_sharded(frame, rt, scene_of, checksums):
 
 
 # ---- bounded stress sweep: every traversal against the oracle on hostile cameras -------------------
-MODES = [(1, "wave"), (2, "bvh"), (3, "wavefront"), (4, "wavefront+tight")]
+MODES = [(1, "wave"), (2, "bvh"), (3, "wavefront"), (4, "wavefront+tight"), (5, "bvh+coop-shadows")]
 
 
 def _stress_cameras(g, ext, n, w, h):
@@ -113,7 +113,7 @@ def _stress_cameras(g, ext, n, w, h):
 
 @pytest.mark.parametrize("name,params,depth,ext", [("TeapotTable", None, 8, 12.0), ("Soup", [8000, 80, 8], 4, 60.0)])
 def test_stress_every_traversal_against_the_oracle(name, params, depth, ext, rt, scene_of):
-    """~25 random cameras per scene x 4 traversals, each frame compared with the oracle (not HIP with HIP):
+    """~25 random cameras per scene x 5 kernels, each frame compared with the oracle (not HIP with HIP):
     ids bit-exact, colours within tolerance.  Covers the distance cull and the tight tree's pads on views
     the fixed cases do not have (eye inside the mesh, grazing the mirror floor, axis-aligned rays)."""
     sc = scene_of(name, params)
@@ -123,13 +123,15 @@ def test_stress_every_traversal_against_the_oracle(name, params, depth, ext, rt,
     try:
         for mode, label in MODES:
             rt.set_option(rt.OPTION_TIGHT_TREE, 0 if mode == 3 else 1)
-            rt.set_option(rt.OPTION_WAVEFRONT_MIN_NODES, 0 if mode == 4 else 30000)
-            rt.set_option(rt.OPTION_TRAVERSAL, min(mode, 3))
+            rt.set_option(rt.OPTION_TIGHT_MIN_NODES, 0 if mode == 4 else 1000)
+            rt.set_option(rt.OPTION_COOP_SHADOWS, 1 if mode == 5 else 0)
+            rt.set_option(rt.OPTION_TRAVERSAL, {1: 1, 2: 2, 3: 3, 4: 3, 5: 2}[mode])
             rt.SendPrimitivesToShader(sc)
             for k, (cam, ref) in enumerate(zip(cams, refs)):
                 rt.PrepareRenderOpenGL(cam)
                 assert_frame_matches(rt.RenderGL(depth), ref, f"{name} {label} camera {k}")
     finally:
         rt.set_option(rt.OPTION_TIGHT_TREE, 1)
-        rt.set_option(rt.OPTION_WAVEFRONT_MIN_NODES, 1000)
+        rt.set_option(rt.OPTION_TIGHT_MIN_NODES, 1000)
+        rt.set_option(rt.OPTION_COOP_SHADOWS, 0)
         rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)

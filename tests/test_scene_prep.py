@@ -22,7 +22,7 @@ def test_reference_scenes_pass_every_precondition(name, params, scene_of):
     assert info["tight_nodes"] == 1 + max(a - 1, 0) + max(b - 1, 0)
     assert 0 < info["tight_levels"] <= 32 and 0 < info["bvh_levels"] <= 32
     assert info["unbounded_triangles"] == (19 if name == "TeapotTable" else 0)
-    small = check_scene(sc)                             # default threshold: only large scenes get it
+    small = check_scene(sc)                             # default threshold (RT_OPTION_TIGHT_MIN_NODES): only large scenes
     assert (small["tight_nodes"] > 0) == (small["n_nodes"] >= 1000)
 
 
