@@ -16,8 +16,14 @@
 // reference formula.  This file builds such a tree with a binned surface-area heuristic; rays with a
 // non-finite origin or 1/d (a zero direction component) do not use it (rt_kernels.h).
 //
-// Node = 64 B = 4 x float4: {lo0.xyz, ref0 | hi0.xyz, ref1 | lo1.xyz, - | hi1.xyz, -}: both child boxes
-// sit in the parent, so one node fetch decides both children.  ref: bit 31 clear = inner node index;
+// Node = 64 B = 4 x float4, both child boxes in the parent (one node fetch decides both children), stored
+// coordinate by coordinate as {child 0, child 1} pairs:
+//     {lo.x0 lo.x1 lo.y0 lo.y1 | lo.z0 lo.z1 hi.x0 hi.x1 | hi.y0 hi.y1 hi.z0 hi.z1 | ref0 ref1 - -}
+// (The pairs were laid out for packed fp32 -- one v_pk_add/mul/fma_f32 per slab parameter of both children.
+// Measured and dropped, DESIGN.md 5.3: a packed instruction takes two issue slots on this GPU, tools/pk_rate.hip,
+// so nothing is gained, and the pair operands cost the staged kernels twice the spills.  The layout stayed: the
+// refs sit together in the last quarter, and the staged pipeline measured 4 % faster with it.)
+// ref: bit 31 clear = inner node index;
 // bit 31 set = leaf, bits 30..0 as rtf meta (kind, slot count, first slot); NOCULL below.  Node 0 holds the root box
 // as child 0 and an empty leaf (or the tree of the unbounded leaves, NOCULL below) as child 1, so a
 // traversal always starts with `cur = 0`.
@@ -34,14 +40,17 @@
 namespace rtb {
 
 struct Node {
-    float lo0[3];
-    uint32_t ref0;
-    float hi0[3];
-    uint32_t ref1;
-    float lo1[3];
-    uint32_t pad0;
-    float hi1[3];
-    uint32_t pad1;
+    float lo[3][2];  // [axis][child]   (float4 0 and the first half of float4 1)
+    float hi[3][2];  // [axis][child]   (second half of float4 1 and float4 2)
+    uint32_t ref[2];
+    uint32_t pad[2];
+    void set_child(int c, const float* l, const float* h, uint32_t r) {
+        for (int k = 0; k < 3; k++) lo[k][c] = l[k], hi[k][c] = h[k];
+        ref[c] = r;
+    }
+    void get_box(int c, float* l, float* h) const {
+        for (int k = 0; k < 3; k++) l[k] = lo[k][c], h[k] = hi[k][c];
+    }
 };
 static_assert(sizeof(Node) == 64, "BVH node is 64 B");
 
@@ -182,8 +191,8 @@ struct Builder {
             rr = build(mid, e, level + 1, &r, right_base, 0);
         }
         Node& nd = out.nodes[me];
-        for (int k = 0; k < 3; k++) nd.lo0[k] = l.lo[k], nd.hi0[k] = l.hi[k], nd.lo1[k] = r.lo[k], nd.hi1[k] = r.hi[k];
-        nd.ref0 = rl, nd.ref1 = rr, nd.pad0 = nd.pad1 = 0;
+        nd.set_child(0, l.lo, l.hi, rl), nd.set_child(1, r.lo, r.hi, rr);
+        nd.pad[0] = nd.pad[1] = 0;
         box->grow(l.lo, l.hi);
         box->grow(r.lo, r.hi);
         return me | ((ref_nocull(rl) || ref_nocull(rr)) ? NOCULL : 0u);
@@ -218,12 +227,8 @@ inline void build_items(std::vector<Item>& items, size_t split, Bvh* out) {
     }
     out->levels = bld.levels.load();
     Node& h = out->nodes[0];
-    for (int k = 0; k < 3; k++) {
-        h.lo0[k] = box[0].lo[k], h.hi0[k] = box[0].hi[k];
-        h.lo1[k] = box[1].lo[k], h.hi1[k] = box[1].hi[k];
-    }
-    h.ref0 = ref[0], h.ref1 = ref[1];
-    h.pad0 = h.pad1 = 0;
+    h.set_child(0, box[0].lo, box[0].hi, ref[0]), h.set_child(1, box[1].lo, box[1].hi, ref[1]);
+    h.pad[0] = h.pad[1] = 0;
 }
 }  // namespace detail
 

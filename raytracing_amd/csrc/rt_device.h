@@ -24,7 +24,8 @@ using namespace rtm;
 //   [0, 2*n_nodes)                      2 x float4 per node (rtf::FlatNode)
 //   [tri_off, tri_off + 3*n_tri_slots)  3 x float4 per triangle slot: A.xyz B.x | B.yz C.xy | C.z N.xyz
 //   [sph_off, sph_off + n_sph_slots)    1 x float4 per sphere slot: center.xyz radius
-//   [bvh_off, geom_float4s)             4 x float4 per node of the re-treed leaves (rt_bvh.h)
+//   [bvh_off, geom_float4s)             4 x float4 per node of the re-treed leaves (rt_bvh.h: child boxes as
+//                                       per-coordinate {child 0, child 1} pairs, then the two refs)
 //   [geom_float4s, ...)                 4 x float4 per node of the tight tree, if built (large scenes)
 // The part from tri_off on is what the LDS-resident kernel copies into a workgroup's LDS.
 struct DevScene {
@@ -86,6 +87,10 @@ struct GeomBvhT {
     __device__ __forceinline__ float4 bvh_node(uint32_t i, int k) const {
         return bvh[4 * (size_t)(UNB ? (i & rtb::INDEX_MASK) : i) + k];
     }
+    // the two child refs: the first 8 bytes of the node's last quarter
+    __device__ __forceinline__ uint2 bvh_refs(uint32_t i) const {
+        return *(const uint2*)(bvh + 4 * (size_t)(UNB ? (i & rtb::INDEX_MASK) : i) + 3);
+    }
 };
 // dynamic LDS of the kernels that use it; named directly (not through a generic pointer) so that
 // every access is a ds_read / ds_write, never a flat access
@@ -106,6 +111,10 @@ struct GeomBvhLds {
     __device__ __forceinline__ float4 tri(int slot, int k) const { return rt_lds[3 * slot + k]; }
     __device__ __forceinline__ float4 sphere(int slot) const { return rt_lds[sph_l + slot]; }
     __device__ __forceinline__ float4 bvh_node(uint32_t i, int k) const { return rt_lds[bvh_l + 4 * (int)(i & rtb::INDEX_MASK) + k]; }
+    __device__ __forceinline__ uint2 bvh_refs(uint32_t i) const {
+        const float4 q = rt_lds[bvh_l + 4 * (int)(i & rtb::INDEX_MASK) + 3];
+        return make_uint2(__float_as_uint(q.x), __float_as_uint(q.y));
+    }
 };
 template <class G>
 struct is_bvh {
@@ -268,6 +277,12 @@ __device__ __forceinline__ bool make_tight_ray(BoxRay& r, V3 extent, float tight
     const bool ok = (E <= tight_e) & (fabsf(r.inv.x) <= big) & (fabsf(r.inv.y) <= big) & (fabsf(r.inv.z) <= big);
     if (ok) r.padinv = v3(-(r.o.x * r.inv.x), -(r.o.y * r.inv.y), -(r.o.z * r.inv.z));
     return ok;
+}
+
+// child 0's box of a node as the scalar tests take it
+__device__ __forceinline__ void node_child0(float4 q0, float4 q1, float4 q2, float4* lo, float4* hi) {
+    *lo = make_float4(q0.x, q0.z, q1.x, 0.0f);
+    *hi = make_float4(q1.z, q2.x, q2.z, 0.0f);
 }
 
 // IntersectTriangle for the fast kernels: same arithmetic, but the three edge tests are only

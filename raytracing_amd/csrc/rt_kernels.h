@@ -120,9 +120,10 @@ __device__ __forceinline__ void wave_walk(const G& g, int n_nodes, const BoxRay&
 // whether the ray walks anything at all.  Returns the root's ref or NONE.
 template <class G>
 __device__ __forceinline__ uint32_t bvh_enter(const G& g, const BoxRay& br, float t_lo, float t_hi) {
-    const float4 q0 = g.bvh_node(0, 0), q1 = g.bvh_node(0, 1);
-    const uint32_t r0 = __float_as_uint(q0.w);
-    return IntersectBoundingBoxCull(br, q0, q1, t_lo, t_hi, nullptr, G::unbounded && rtb::ref_nocull(r0)) ? r0 : 0xFFFFFFFFu;
+    float4 lo, hi;
+    node_child0(g.bvh_node(0, 0), g.bvh_node(0, 1), g.bvh_node(0, 2), &lo, &hi);
+    const uint32_t r0 = g.bvh_refs(0).x;
+    return IntersectBoundingBoxCull(br, lo, hi, t_lo, t_hi, nullptr, G::unbounded && rtb::ref_nocull(r0)) ? r0 : 0xFFFFFFFFu;
 }
 
 template <class G, class LeafSphere, class LeafTri, class Done, class THi>
@@ -140,12 +141,15 @@ __device__ __forceinline__ void bvh_walk(const G& g, const BoxRay& br, bool aliv
             rt_diag[0]++;
             if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) rt_diag[2]++;
 #endif
-            const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2), q3 = g.bvh_node(cur, 3);
+            const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2);
+            const uint2 refs = g.bvh_refs(cur);
             const float th = t_hi();
             float e0, e1;
-            const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
-            const bool h0 = IntersectBoundingBoxCull(br, q0, q1, t_lo, th, &e0, G::unbounded && rtb::ref_nocull(r0));
-            const bool h1 = IntersectBoundingBoxCull(br, q2, q3, t_lo, th, &e1, G::unbounded && rtb::ref_nocull(r1));
+            const uint32_t r0 = refs.x, r1 = refs.y;
+            const float4 lo0 = make_float4(q0.x, q0.z, q1.x, 0), hi0 = make_float4(q1.z, q2.x, q2.z, 0);
+            const float4 lo1 = make_float4(q0.y, q0.w, q1.y, 0), hi1 = make_float4(q1.w, q2.y, q2.w, 0);
+            const bool h0 = IntersectBoundingBoxCull(br, lo0, hi0, t_lo, th, &e0, G::unbounded && rtb::ref_nocull(r0));
+            const bool h1 = IntersectBoundingBoxCull(br, lo1, hi1, t_lo, th, &e1, G::unbounded && rtb::ref_nocull(r1));
             if (h0 & h1) {
                 const bool swap = e1 < e0;
                 stk[64 * sp++] = swap ? r0 : r1;

@@ -550,8 +550,8 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     {  // the tight nodes follow the leaf tree's in one array: inner refs become indices of that array
         const uint32_t base = (uint32_t)prep.bvh.nodes.size();
         for (rtb::Node& nd : prep.tight.nodes) {
-            if (!(nd.ref0 & rtb::LEAF)) nd.ref0 += base;
-            if (!(nd.ref1 & rtb::LEAF)) nd.ref1 += base;
+            for (uint32_t& r : nd.ref)
+                if (!(r & rtb::LEAF)) r += base;
         }
     }
     if (ctx->multi) return multi_upload(ctx, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);

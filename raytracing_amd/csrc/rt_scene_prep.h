@@ -164,9 +164,14 @@ inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, cons
         for (int k = 0; k < 3; k++) td.lo[k] = lo[k], td.hi[k] = hi[k];
         stack.push_back(td);
     };
-    const rtb::Node& h = t.nodes[0];
-    push(h.ref0, h.lo0, h.hi0, 1);
-    push(h.ref1, h.lo1, h.hi1, 1);
+    auto push_children = [&](const rtb::Node& nd, int level) {
+        for (int c = 0; c < 2; c++) {
+            float lo[3], hi[3];
+            nd.get_box(c, lo, hi);
+            push(nd.ref[c], lo, hi, level);
+        }
+    };
+    push_children(t.nodes[0], 1);
     size_t visited = 1;
     while (!stack.empty()) {
         const Todo td = stack.back();
@@ -217,11 +222,10 @@ inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, cons
         visited++;
         const rtb::Node& nd = t.nodes[idx];
         for (int k = 0; k < 3; k++)
-            if (std::fmin(nd.lo0[k], nd.lo1[k]) != td.lo[k] || std::fmax(nd.hi0[k], nd.hi1[k]) != td.hi[k])
+            if (std::fmin(nd.lo[k][0], nd.lo[k][1]) != td.lo[k] || std::fmax(nd.hi[k][0], nd.hi[k][1]) != td.hi[k])
                 return "inner box is not the exact union of its children";
-        if (rtb::ref_nocull(td.ref) != (rtb::ref_nocull(nd.ref0) || rtb::ref_nocull(nd.ref1))) return "never-cull mark not propagated";
-        push(nd.ref0, nd.lo0, nd.hi0, td.level + 1);
-        push(nd.ref1, nd.lo1, nd.hi1, td.level + 1);
+        if (rtb::ref_nocull(td.ref) != (rtb::ref_nocull(nd.ref[0]) || rtb::ref_nocull(nd.ref[1]))) return "never-cull mark not propagated";
+        push_children(nd, td.level + 1);
     }
     if (visited != t.nodes.size()) return "unreachable or shared nodes";
     if (tight_of) {

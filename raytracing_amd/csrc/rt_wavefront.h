@@ -166,17 +166,23 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
 #pragma unroll
             for (int rep = 0; rep < RT_WF_NODE_REPS; rep++)
             if (!(cur & LEAF)) {  // node step (NONE has the leaf bit)
-                const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2), q3 = g.bvh_node(cur, 3);
+                const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2);
+                const uint2 refs = g.bvh_refs(cur);
                 const float th = job.t_hi();
                 float e0, e1;
-                const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+                const uint32_t r0 = refs.x, r1 = refs.y;
+                const bool nc0 = G::unbounded && rtb::ref_nocull(r0), nc1 = G::unbounded && rtb::ref_nocull(r1);
                 bool h0, h1;
+                // (the scalar tests on the unpacked boxes: the packed pair forms of rt_device.h cost these kernels,
+                // which run at an 80-VGPR cap, twice the spills -- Soup1M 4K 57 -> 100 ms)
+                const float4 lo0 = make_float4(q0.x, q0.z, q1.x, 0), hi0 = make_float4(q1.z, q2.x, q2.z, 0);
+                const float4 lo1 = make_float4(q0.y, q0.w, q1.y, 0), hi1 = make_float4(q1.w, q2.y, q2.w, 0);
                 if (job.tight) {  // conservative filter (rt_bvh.h build_tight)
-                    h0 = SlabHit(job.br, q0, q1, job.t_lo, th, &e0, G::unbounded && rtb::ref_nocull(r0));
-                    h1 = SlabHit(job.br, q2, q3, job.t_lo, th, &e1, G::unbounded && rtb::ref_nocull(r1));
+                    h0 = SlabHit(job.br, lo0, hi0, job.t_lo, th, &e0, nc0);
+                    h1 = SlabHit(job.br, lo1, hi1, job.t_lo, th, &e1, nc1);
                 } else {  // the reference's test on the reference's leaf boxes
-                    h0 = IntersectBoundingBoxCull(job.br, q0, q1, job.t_lo, th, &e0, G::unbounded && rtb::ref_nocull(r0));
-                    h1 = IntersectBoundingBoxCull(job.br, q2, q3, job.t_lo, th, &e1, G::unbounded && rtb::ref_nocull(r1));
+                    h0 = IntersectBoundingBoxCull(job.br, lo0, hi0, job.t_lo, th, &e0, nc0);
+                    h1 = IntersectBoundingBoxCull(job.br, lo1, hi1, job.t_lo, th, &e1, nc1);
                 }
                 h0 &= r0 != LEAF, h1 &= r1 != LEAF;
                 if (h0 & h1) {
