@@ -47,7 +47,8 @@ struct DevScene {
     // re-treed leaves (rt_bvh.h): 4 x float4 per node, node 0 = root holder; null if not built.
     // They sit at the end of the geometry image (bvh == geom + bvh_off).
     const float4* bvh;
-    int32_t bvh_levels;  // stack entries a traversal can need (either tree)
+    int32_t bvh_levels;  // stack entries per lane of the staged pipeline (the deeper of the two trees)
+    int32_t leaf_levels; // stack entries per lane of the megakernels, which walk the re-treed leaves only
     int32_t bvh_off;
     // tight per-primitive tree (rt_bvh.h build_tight), stored behind the image as further nodes of
     // `bvh`: its root holder is node tight_root (0 = not built / not used).  Only rays with

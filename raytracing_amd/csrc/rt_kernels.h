@@ -834,7 +834,7 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 }
 
 // ---- large scenes: per-lane ordered traversal of the re-treed leaves, stacks in LDS ----------------
-// Same pixel mapping as k_render; dynamic LDS = BLOCK_WAVES * 64 lanes * bvh_levels dwords.
+// Same pixel mapping as k_render; dynamic LDS = BLOCK_WAVES * 64 lanes * leaf_levels dwords.
 #ifndef RT_BVH_WAVES_PER_EU
 #define RT_BVH_WAVES_PER_EU 3
 #endif
@@ -858,15 +858,15 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES)
     const bool live = in_image && x < a.width && r < a.local_rows && y < a.height;
 #ifdef RT_DIAG_STEPS
     int diag[4] = {0, 0, 0, 0};
-    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.bvh_levels + lane, diag};
+    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.leaf_levels + lane, diag};
 #else
-    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.bvh_levels + lane};
+    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, wave * 64 * a.scene.leaf_levels + lane};
 #endif
 #ifdef RT_DIAG_WAVE_TIMES  // diagnostic build only: id planes receive each wave's start / end on the 100 MHz clock
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if (COOP) {  // every lane takes part, with or without a pixel
-        const int coop_base = BLOCK_WAVES * 64 * a.scene.bvh_levels + wave * COOP_DWORDS;
+        const int coop_base = BLOCK_WAVES * 64 * a.scene.leaf_levels + wave * COOP_DWORDS;
         const PixelOut p = shade_pixel_coop(a.scene, g, coop_base, cam, (float)x + 0.5f, (float)y + 0.5f, a.max_bounces, live);
         if (live) store_pixel(a, frame, x, r, p);
     } else if (live) {
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(LDS_BLOCK) void k_render_bvh_lds(const RenderArgs a
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const GeomBvhLds g{a.scene.geom, a.scene.sph_off - a.scene.tri_off, a.scene.bvh_off - a.scene.tri_off,
-                       n_copy * 4 + wave * 64 * a.scene.bvh_levels + lane};
+                       n_copy * 4 + wave * 64 * a.scene.leaf_levels + lane};
     const int per = a.supertile * a.supertile;
     const int n_super = ((a.tiles_x + a.supertile - 1) / a.supertile) * ((a.tiles_y + a.supertile - 1) / a.supertile);
     const unsigned int n_tickets = (unsigned int)(n_super * per);

@@ -490,6 +490,7 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
 
     s.bvh = bvh.nodes.empty() ? nullptr : (const float4*)ctx->geom.p + bvh_off;
     s.bvh_levels = std::max(bvh.levels, tight.nodes.empty() ? 0 : tight.levels);
+    s.leaf_levels = bvh.levels;
     s.bvh_off = (int32_t)bvh_off;
     for (int k = 0; k < 3; k++) s.root_lo[k] = s.root_hi[k] = 0.0f;
     if (!flat.nodes.empty()) {
@@ -511,8 +512,8 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     inf.device_bytes = (int64_t)(flat.nodes.size() * 32 + (size_t)n_ts * 52 + (size_t)n_ss * 20 +
                                  (size_t)n_planes * 96 + (size_t)n_spheres * 48 + (size_t)n_triangles * 96 +
                                  (size_t)lights_len * 4);
-    // k_render_bvh_lds strides its per-lane stacks by scene.bvh_levels (the deeper of the two trees)
-    ctx->lds_bytes = (geom_f4 - tri_off) * 16 + (size_t)LDS_BLOCK * std::max(s.bvh_levels, 1) * 4;
+    // k_render_bvh_lds strides its per-lane stacks by scene.leaf_levels (it walks the re-treed leaves only)
+    ctx->lds_bytes = (geom_f4 - tri_off) * 16 + (size_t)LDS_BLOCK * std::max(s.leaf_levels, 1) * 4;
     inf.lds_scene_bytes = (int64_t)ctx->lds_bytes;
     inf.bvh_nodes = (int64_t)bvh.nodes.size();
     inf.bvh_levels = bvh.levels;
@@ -818,7 +819,7 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
         if ((rc = chain_end(ctx, st)) != RT_OK) return rc;
     } else if (use_bvh) {
         const bool unb = ctx->info.unbounded_triangles > 0;
-        const size_t stacks = (size_t)BLOCK_WAVES * 64 * a.scene.bvh_levels * 4;
+        const size_t stacks = (size_t)BLOCK_WAVES * 64 * a.scene.leaf_levels * 4;
         const bool coop = ctx->coop_shadows && a.scene.lights_len / 6 <= COOP_MAX_LIGHTS && a.scene.lights_len > 0;
         void (*kern)(const RenderArgs) = coop ? (unb ? k_render_bvh<true, true> : k_render_bvh<false, true>)
                                               : (unb ? k_render_bvh<true, false> : k_render_bvh<false, false>);
@@ -1000,3 +1001,11 @@ int rt_eval_triangle(rt_ctx* ctx, int n, const float* o3, const float* d3, const
 }  // extern "C"
 
 #include "rt_multi.h"
+
+#ifdef RT_DIAG_WF  // diagnostic build only: read and clear the trace stages' trip counters (tools/diag_wf.py)
+extern "C" int rt_debug_wf_diag(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rtd::rt_wf_diag), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long zero[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(rtd::rt_wf_diag), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -117,8 +117,17 @@ __device__ __forceinline__ uint32_t wf_draw(uint32_t* head, uint32_t total, bool
 // they draw new rays (wf_draw).  Job supplies the ray: setup(k) -> bool (needs a traversal),
 // t_lo, t_hi(), sphere(slot), tri(slot), done(), finish().
 // ------------------------------------------------------------------------------------------
+#ifdef RT_DIAG_WF  // diagnostic build only (tools/diag_wf.py): where the lanes of the trace stages spend their trips
+__device__ unsigned long long rt_wf_diag[16];
+#define WF_DIAG(i, v) diag[i] += (unsigned long long)(v)
+#else
+#define WF_DIAG(i, v) ((void)0)
+#endif
 template <class G, class Job>
 __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t total, Job& job) {
+#ifdef RT_DIAG_WF
+    unsigned long long diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     constexpr uint32_t NONE = 0xFFFFFFFFu, LEAF = 0x80000000u;
     uint32_t* const stk = (uint32_t*)rt_lds + g.stack_base;
     bool exhausted = false;
@@ -158,11 +167,13 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
         }
         if (n_idle == 64) {
             if (exhausted) break;
+            WF_DIAG(7, 1);
             continue;
         }
         const bool at_leaf = cur != NONE && (cur & LEAF);
         const int n_leaf = __popcll(__ballot(at_leaf));
         if (64 - n_idle - n_leaf >= RT_WF_VOTE * n_leaf) {
+            WF_DIAG(0, 1), WF_DIAG(1, 64 - n_idle - n_leaf), WF_DIAG(2, n_idle), WF_DIAG(3, n_leaf);
 #pragma unroll
             for (int rep = 0; rep < RT_WF_NODE_REPS; rep++)
             if (!(cur & LEAF)) {  // node step (NONE has the leaf bit)
@@ -198,7 +209,7 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
                     cur = NONE;
                 }
             }
-        } else if (at_leaf) {  // one primitive of the leaf
+        } else if (WF_DIAG(4, 1), WF_DIAG(5, n_leaf), WF_DIAG(6, n_idle), at_leaf) {  // one primitive of the leaf
             const int kind = (cur >> 29) & 3;
             const int count = (cur >> 24) & 31;
             const int slot = (int)(cur & 0xFFFFFF) + lk;
@@ -219,6 +230,10 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
             }
         }
     }
+#ifdef RT_DIAG_WF
+    if ((int)__lane_id() == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(&rt_wf_diag[Job::DIAG_BASE + k], diag[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -226,6 +241,7 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
 // ------------------------------------------------------------------------------------------
 template <class G>
 struct WfClosestJob {
+    static constexpr int DIAG_BASE = 0;
     const WfArgs& a;
     const G& g;
     float t_lo;  // minDistance: 0 for the primary ray, epsilon after a bounce
@@ -320,6 +336,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_
 // ------------------------------------------------------------------------------------------
 template <class G>
 struct WfAnyJob {
+    static constexpr int DIAG_BASE = 8;
     const WfArgs& a;
     const G& g;
     uint32_t n_active;

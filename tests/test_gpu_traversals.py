@@ -412,9 +412,9 @@ def test_edge_scenes_in_every_traversal(mode, label, rt_mode, scene_of):
 @pytest.mark.parametrize("tight_everywhere", [False, True], ids=["leaf-tree-only", "with-tight-tree"])
 @pytest.mark.parametrize("name,depth", [("TestScene1", 10), ("TeapotTable", 8)])
 def test_lds_resident_kernel_matches_the_oracle(name, depth, tight_everywhere, rt_mode, scene_of):
-    """RT_OPTION_USE_LDS (k_render_bvh_lds, GeomBvhLds): the per-lane stacks are strided by the deeper of the
-    two trees, so the LDS allocation must be sized with it (a scene that also gets a tight tree used to
-    overflow it for the upper waves)."""
+    """RT_OPTION_USE_LDS (k_render_bvh_lds, GeomBvhLds): the kernel's per-lane stacks and the host's LDS allocation
+    must use the same depth -- the leaf tree's, the only tree it walks -- whether or not the scene also has a tight
+    tree (they once disagreed, and the upper waves wrote past the allocation)."""
     rt = rt_mode
     sc = scene_of(name)
     rt.set_option(rt.OPTION_TIGHT_TREE, 1)
@@ -429,8 +429,6 @@ def test_lds_resident_kernel_matches_the_oracle(name, depth, tight_everywhere, r
         info = rt.scene_info()
         assert 0 < info["lds_scene_bytes"] <= 160 * 1024, "the scene must actually fit, or the LDS kernel did not run"
         assert (info["tight_nodes"] > 0) == tight_everywhere
-        if tight_everywhere:
-            assert info["tight_levels"] >= info["bvh_levels"]
     finally:
         rt.set_option(rt.OPTION_USE_LDS, 0)
         rt.set_option(rt.OPTION_TIGHT_MIN_NODES, 1000)
