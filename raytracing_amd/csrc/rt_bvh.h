@@ -317,7 +317,8 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
         float f = (float)x;
         return (double)f < x ? std::nextafterf(f, INFINITY) : f;
     };
-    for (size_t ni = 0; ni < flat.nodes.size(); ni++) {
+    auto fill = [&](size_t n0, size_t n1, std::vector<detail::Item>& items, std::vector<detail::Item>& sphere_items) {
+    for (size_t ni = n0; ni < n1; ni++) {
         const rtf::FlatNode& fn = flat.nodes[ni];
         const int count = (fn.meta >> 24) & 31, first = (int)(fn.meta & 0xFFFFFF);
         int kind = (fn.meta >> 29) & 3;
@@ -365,6 +366,24 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
             }
             for (int c = 0; c < 3; c++) it.lo[c] = down(lo[c] - pad), it.hi[c] = up(hi[c] + pad);
             (kind == rtf::KIND_TRI ? items : sphere_items).push_back(it);
+        }
+    }
+    };
+    // leaf records are independent (each slot belongs to one leaf): node ranges on up to 16 threads, results
+    // concatenated in range order, so the item order -- and with it the tree -- does not depend on the thread count
+    const size_t n_nodes = flat.nodes.size();
+    const int n_threads = n_nodes < (1u << 16) ? 1 : (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_threads == 1) {
+        fill(0, n_nodes, items, sphere_items);
+    } else {
+        std::vector<std::vector<detail::Item>> part(n_threads), sphere_part(n_threads);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; t++)
+            pool.emplace_back([&, t] { fill(n_nodes * t / n_threads, n_nodes * (t + 1) / n_threads, part[t], sphere_part[t]); });
+        for (std::thread& th : pool) th.join();
+        for (int t = 0; t < n_threads; t++) {
+            items.insert(items.end(), part[t].begin(), part[t].end());
+            sphere_items.insert(sphere_items.end(), sphere_part[t].begin(), sphere_part[t].end());
         }
     }
     const size_t split = items.size();

@@ -5,9 +5,13 @@
 // is what the CPU tests use.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_bvh.h"
@@ -56,12 +60,12 @@ inline bool triangle_is_unbounded(const float* rec) {
 // Distance cull precondition: boxes nested, every primitive inside its leaf box (within a slack far
 // below the cull's pad), stored triangle normals perpendicular to their triangles.  Also collects the
 // unbounded triangles.  Returns false if the cull must stay off.
-inline bool check_containment(const rtf::Flat& flat, const unsigned char* spheres, const unsigned char* triangles,
-                              const float extent[3], std::vector<uint8_t>* tri_unbounded,
-                              std::vector<int32_t>* unbounded_leaves) {
-    if (!flat.nested) return false;
-    const float slack = std::fmax(extent[0], std::fmax(extent[1], extent[2])) * (1.0f / 4096.0f);
-    for (size_t ni = 0; ni < flat.nodes.size(); ni++) {
+// Leaf records are independent: the upload runs this over node ranges on up to 16 threads (a million primitives
+// take 0.17 s on one core).
+inline bool check_containment_range(const rtf::Flat& flat, const unsigned char* spheres, const unsigned char* triangles,
+                                    float slack, size_t n0, size_t n1, std::vector<uint8_t>* tri_unbounded,
+                                    std::vector<int32_t>* unbounded_leaves) {
+    for (size_t ni = n0; ni < n1; ni++) {
         const rtf::FlatNode& fn = flat.nodes[ni];
         const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = fn.meta & 0xFFFFFF;
         if (kind == rtf::KIND_BRANCH) continue;
@@ -93,10 +97,33 @@ inline bool check_containment(const rtf::Flat& flat, const unsigned char* sphere
                 if (!(off <= 4.0 * slack * nn)) return false;
             }
             if (triangle_is_unbounded(rec)) {
-                (*tri_unbounded)[first + k] = 1;
+                (*tri_unbounded)[first + k] = 1;  // slots of different leaves: no two threads write the same byte
                 unbounded_leaves->push_back((int32_t)ni);
             }
         }
+    }
+    return true;
+}
+inline bool check_containment(const rtf::Flat& flat, const unsigned char* spheres, const unsigned char* triangles,
+                              const float extent[3], std::vector<uint8_t>* tri_unbounded,
+                              std::vector<int32_t>* unbounded_leaves) {
+    if (!flat.nested) return false;
+    const float slack = std::fmax(extent[0], std::fmax(extent[1], extent[2])) * (1.0f / 4096.0f);
+    const size_t n = flat.nodes.size();
+    const int n_threads = n < (1u << 16) ? 1 : (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_threads == 1) return check_containment_range(flat, spheres, triangles, slack, 0, n, tri_unbounded, unbounded_leaves);
+    std::vector<std::vector<int32_t>> found(n_threads);
+    std::vector<char> ok(n_threads, 1);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; t++)
+        pool.emplace_back([&, t] {
+            ok[t] = check_containment_range(flat, spheres, triangles, slack, n * t / n_threads, n * (t + 1) / n_threads,
+                                            tri_unbounded, &found[t]) ? 1 : 0;
+        });
+    for (std::thread& th : pool) th.join();
+    for (int t = 0; t < n_threads; t++) {
+        if (!ok[t]) return false;
+        unbounded_leaves->insert(unbounded_leaves->end(), found[t].begin(), found[t].end());  // ranges in order: sorted
     }
     return true;
 }
@@ -104,9 +131,19 @@ inline bool check_containment(const rtf::Flat& flat, const unsigned char* sphere
 // Returns rtf::FLATTEN_* (0 = ok).  spheres / triangles: the uploaded SphereStruct / TriangleStruct arrays.
 inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned char* triangles, int n_triangles,
                    const float* accel, int64_t accel_len, const Options& opt, Prepared* out, std::string* err) {
+    // RT_PREP_TIMING=1 (development): wall time of each phase on stderr
+    const bool timing = std::getenv("RT_PREP_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rt prepare] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     rtf::Flat& flat = out->flat;
     const int rc = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &flat, err);
     if (rc != rtf::FLATTEN_OK) return rc;
+    lap("validate + flatten");
     for (int k = 0; k < 3; k++) out->extent[k] = 0.0f;
     if (!flat.nodes.empty()) {
         const rtf::FlatNode& root = flat.nodes[0];
@@ -120,9 +157,11 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
     out->unbounded = (int64_t)std::count(out->tri_unbounded.begin(), out->tri_unbounded.end(), 1);
     if (out->contained)
         for (int32_t leaf : unbounded_leaves) rtf::mark_unbounded(&flat, leaf);
+    lap("cull preconditions");
     // re-treed leaves for the per-lane kernels (only for nested trees, rt_bvh.h)
     out->bvh = rtb::Bvh();
     if (flat.nested) rtb::build(flat, &out->bvh);
+    lap("re-tree the leaves (SAH)");
     // tight per-primitive tree for the staged pipeline's rays (rt_bvh.h build_tight): large scenes whose
     // primitives were just verified to sit inside their leaves with matching normals
     out->tight = rtb::Bvh();
@@ -139,6 +178,7 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
         rtb::build_tight(flat, in, &out->tight, &out->tri_slot_leaf, &out->sphere_slot_leaf);
         if (out->tight.levels > rtb::MAX_LEVELS) out->tight = rtb::Bvh();
     }
+    lap("tight tree (SAH)");
     return rtf::FLATTEN_OK;
 }
 
