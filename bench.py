@@ -47,6 +47,8 @@ KERNEL_OF = {1: "k_render<false> (wave-cooperative walk)", 2: "k_render_bvh (per
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2.4 GHz
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
+VALU_CYCLES_PER_INST = 2.5   # measured, tools/pk_rate.hip (profiles/r02_pk_rate.txt): a wave64 v_mul/v_fma_f32 issues every
+                             # 2.4-2.65 cycles per SIMD (a packed fp32 instruction every 4.9: two slots)
 BAND_ROWS = 8  # one 8x8 tile row per band: finest interleave of sky / mesh / floor rows over the ranks
 
 WORKLOADS = {
@@ -179,8 +181,8 @@ def roofline_of(workload, stats, width, height, ms, traversal, share=1.0):
     valu = {"achieved_tflops": round(tf, 2), "peak_tflops": FP32_VECTOR_PEAK_TF, "frac": round(tf / FP32_VECTOR_PEAK_TF, 4),
             "algorithmic_flops_per_launch": int(alg_flops)}
     if prof.get("SQ_INSTS_VALU"):
-        # issued VALU wave-instructions x 4 cycles each, over the SIMD-cycles of the launch
-        valu["issue_occupancy"] = round(prof["SQ_INSTS_VALU"] * share * 4 / (N_SIMD * ms * 1e-3 * CLOCK_HZ), 3)
+        # issued VALU wave-instructions x the measured issue interval, over the SIMD-cycles of the launch
+        valu["issue_occupancy"] = round(prof["SQ_INSTS_VALU"] * share * VALU_CYCLES_PER_INST / (N_SIMD * ms * 1e-3 * CLOCK_HZ), 3)
     if prof.get("SQ_THREAD_CYCLES_VALU") and prof.get("SQ_ACTIVE_INST_VALU"):
         valu["active_lanes"] = round(prof["SQ_THREAD_CYCLES_VALU"] / (64.0 * prof["SQ_ACTIVE_INST_VALU"]), 3)
     hbm = None
