@@ -391,4 +391,94 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
     detail::build_items(items, split, out);
 }
 
+// ------------------------------------------------------------------------------------------
+// The tight tree as the GPU walks it: 32-byte nodes, child boxes on a 16-bit grid.
+//
+// A node step of the staged pipeline is a gather: every lane of a wave fetches its own node, and the
+// cost of a gather instruction is the number of cache lines it touches (64 for 64 rays), whatever its
+// width.  A 64-byte fp32 node takes four such instructions per step; the tight tree is only a filter
+// (see above), so its boxes need not be exact, only conservative: each coordinate is stored as a 16-bit
+// index of a uniform grid over the tree's root box, lower bounds rounded down, upper bounds up
+// (coordinate = base + index * step per axis).  Two 16-byte loads fetch a node, the tree takes half the
+// cache, and a box grows by less than one grid step (extent / 65535 <= 2^-16 E) per side: a quarter of
+// pad_tri.  The traversal never forms the coordinate: with inv_q = step/d and pad_q = (base - o)/d per
+// ray, the slab parameter is fma(index, inv_q, pad_q) (rt_device.h SlabHitQ; rounding < 4 eps E in
+// space, inside the pads' budget like the fp32 form's).
+//   word k (k = 0..2): lower bound of axis k, child 0 in bits 0..15, child 1 in bits 16..31
+//   word 3 + k:        upper bound of axis k, same packing;    words 6, 7: the two refs
+// ------------------------------------------------------------------------------------------
+struct QNode {
+    uint32_t lo[3], hi[3], ref[2];
+};
+static_assert(sizeof(QNode) == 32, "QNode is two 16-byte loads");
+struct QBvh {
+    std::vector<QNode> nodes;
+    float base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
+    // the box child `side` of node i stands for (what the traversal tests against)
+    void get_box(size_t i, int side, double* lo, double* hi) const {
+        for (int c = 0; c < 3; c++) {
+            lo[c] = (double)base[c] + (double)((nodes[i].lo[c] >> (16 * side)) & 0xFFFFu) * (double)step[c];
+            hi[c] = (double)base[c] + (double)((nodes[i].hi[c] >> (16 * side)) & 0xFFFFu) * (double)step[c];
+        }
+    }
+};
+
+// Quantises a tree built by build_tight.  Empty child slots (inverted boxes) stay inverted (lo index 65535,
+// hi index 0).  Returns false if the tree has no finite root box (then there is nothing to walk).
+inline bool quantize(const Bvh& in, QBvh* out) {
+    out->nodes.clear();
+    if (in.nodes.empty()) return false;
+    double rlo[3] = {1e300, 1e300, 1e300}, rhi[3] = {-1e300, -1e300, -1e300};
+    for (int side = 0; side < 2; side++) {
+        float lo[3], hi[3];
+        in.nodes[0].get_box(side, lo, hi);
+        if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) continue;
+        for (int c = 0; c < 3; c++) rlo[c] = std::min(rlo[c], (double)lo[c]), rhi[c] = std::max(rhi[c], (double)hi[c]);
+    }
+    for (int c = 0; c < 3; c++) {
+        if (!(rlo[c] <= rhi[c]) || !std::isfinite(rlo[c]) || !std::isfinite(rhi[c])) return false;
+        out->base[c] = std::nextafterf((float)rlo[c], -INFINITY);
+        // a step that reaches the upper bound with room to spare in index 65535 (never zero: flat scenes)
+        float st = (float)((rhi[c] - (double)out->base[c]) / 65534.0);
+        st = std::nextafterf(st, INFINITY);
+        if (!(st > 0)) st = 1e-30f;
+        out->step[c] = st;
+    }
+    out->nodes.resize(in.nodes.size());
+    const size_t n = in.nodes.size();
+    auto run = [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            QNode q{};
+            for (int side = 0; side < 2; side++) {
+                float lo[3], hi[3];
+                in.nodes[i].get_box(side, lo, hi);
+                const bool empty = !(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]);
+                for (int c = 0; c < 3; c++) {
+                    uint32_t ul = 65535u, uh = 0u;
+                    if (!empty) {
+                        const double B = out->base[c], S = out->step[c];
+                        double l = std::floor(((double)lo[c] - B) / S), h = std::ceil(((double)hi[c] - B) / S);
+                        l = std::min(std::max(l, 0.0), 65535.0), h = std::min(std::max(h, 0.0), 65535.0);
+                        while (l > 0 && B + l * S > (double)lo[c]) l -= 1;
+                        while (h < 65535 && B + h * S < (double)hi[c]) h += 1;
+                        ul = (uint32_t)l, uh = (uint32_t)h;
+                    }
+                    q.lo[c] |= ul << (16 * side), q.hi[c] |= uh << (16 * side);
+                }
+                q.ref[side] = in.nodes[i].ref[side];
+            }
+            out->nodes[i] = q;
+        }
+    };
+    const int n_threads = n < (1u << 16) ? 1 : (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_threads == 1) {
+        run(0, n);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; t++) pool.emplace_back([&, t] { run(n * t / n_threads, n * (t + 1) / n_threads); });
+        for (std::thread& th : pool) th.join();
+    }
+    return true;
+}
+
 }  // namespace rtb

@@ -26,7 +26,7 @@ using namespace rtm;
 //   [sph_off, sph_off + n_sph_slots)    1 x float4 per sphere slot: center.xyz radius
 //   [bvh_off, geom_float4s)             4 x float4 per node of the re-treed leaves (rt_bvh.h: child boxes as
 //                                       per-coordinate {child 0, child 1} pairs, then the two refs)
-//   [geom_float4s, ...)                 4 x float4 per node of the tight tree, if built (large scenes)
+//   [geom_float4s, ...)                 2 x uint4 per node of the tight tree, if built (large scenes; rtb::QNode)
 // The part from tri_off on is what the LDS-resident kernel copies into a workgroup's LDS.
 struct DevScene {
     const float4* geom;
@@ -50,11 +50,13 @@ struct DevScene {
     int32_t bvh_levels;  // stack entries per lane of the staged pipeline (the deeper of the two trees)
     int32_t leaf_levels; // stack entries per lane of the megakernels, which walk the re-treed leaves only
     int32_t bvh_off;
-    // tight per-primitive tree (rt_bvh.h build_tight), stored behind the image as further nodes of
-    // `bvh`: its root holder is node tight_root (0 = not built / not used).  Only rays with
-    // max_k(|o_k| + extent_k) <= tight_e may walk it; *_slot_leaf map a slot to its reference leaf record.
     float root_lo[3], root_hi[3];  // the reference tree's root box (host side: tile priority)
-    uint32_t tight_root;
+    // tight per-primitive tree (rt_bvh.h build_tight), stored behind the image as 32-byte nodes with boxes on a
+    // 16-bit grid (rtb::QNode: coordinate = tight_base + index * tight_step); node 0 is its root holder; null =
+    // not built / not used.  Only rays with max_k(|o_k| + extent_k) <= tight_e may walk it; *_slot_leaf map a
+    // slot to its reference leaf record.
+    const uint4* tight;
+    float tight_base[3], tight_step[3];
     float tight_e;
     const int32_t* tri_slot_leaf;
     const int32_t* sphere_slot_leaf;
@@ -91,6 +93,11 @@ struct GeomBvhT {
     // the two child refs: the first 8 bytes of the node's last quarter
     __device__ __forceinline__ uint2 bvh_refs(uint32_t i) const {
         return *(const uint2*)(bvh + 4 * (size_t)(UNB ? (i & rtb::INDEX_MASK) : i) + 3);
+    }
+    // half k of node i of the tight tree (rtb::QNode; staged pipeline only)
+    const uint4* tight;
+    __device__ __forceinline__ uint4 tight_node(uint32_t i, int k) const {
+        return tight[2 * (size_t)(UNB ? (i & rtb::INDEX_MASK) : i) + k];
     }
 };
 // dynamic LDS of the kernels that use it; named directly (not through a generic pointer) so that
@@ -253,30 +260,41 @@ __device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4
     return !(miss_xy | miss_z | culled);
 }
 
-// Slab test of the tight tree (rt_bvh.h build_tight).  NOT the reference's formula and not meant to
-// be: the tight boxes are padded at build time so that this test, with its own rounding (fma form,
-// < 6 eps E in space), never rejects a box whose primitive's test can accept a t in [t_lo, t_hi];
-// exactness is restored by the leaf-box check on accepted hits (rt_wavefront.h).  Requires
-// make_tight_ray; finite everywhere for |1/d| <= 1e30 and coordinates <= 4e6.
+// Slab test of the tight tree (rt_bvh.h build_tight, quantize).  NOT the reference's formula and not meant to
+// be: the tight boxes are padded at build time so that this test, with its own rounding (grid coordinates, fma
+// form: < 4 eps E in space), never rejects a box whose primitive's test can accept a t in [t_lo, t_hi];
+// exactness is restored by the leaf-box check on accepted hits (rt_wavefront.h).  Requires make_tight_ray;
+// finite everywhere for |1/d| <= 1e30 and coordinates <= 4e6.
+// lo / hi: the node's words of the three lower / upper bounds; SIDE picks the child (its 16-bit half).
 // nocull: an unbounded triangle lies below (rtb::ref_nocull): the reference accepts it wherever the ray's LINE
 // passes its leaf box, so only the line test applies, not the distance window.
-__device__ __forceinline__ bool SlabHit(const BoxRay& r, float4 lo, float4 hi, float t_lo, float t_hi, float* entry,
-                                        bool nocull = false) {
-    const float x0 = __builtin_fmaf(lo.x, r.inv.x, r.padinv.x), x1 = __builtin_fmaf(hi.x, r.inv.x, r.padinv.x);
-    const float y0 = __builtin_fmaf(lo.y, r.inv.y, r.padinv.y), y1 = __builtin_fmaf(hi.y, r.inv.y, r.padinv.y);
-    const float z0 = __builtin_fmaf(lo.z, r.inv.z, r.padinv.z), z1 = __builtin_fmaf(hi.z, r.inv.z, r.padinv.z);
+template <int SIDE>
+__device__ __forceinline__ float grid_coord(uint32_t w) {
+    return (float)(SIDE ? (w >> 16) : (w & 0xFFFFu));  // one v_cvt_f32_u32 with a word select (SDWA)
+}
+template <int SIDE>
+__device__ __forceinline__ bool SlabHitQ(const BoxRay& r, uint32_t lox, uint32_t loy, uint32_t loz, uint32_t hix,
+                                         uint32_t hiy, uint32_t hiz, float t_lo, float t_hi, float* entry, bool nocull = false) {
+    const float x0 = __builtin_fmaf(grid_coord<SIDE>(lox), r.inv.x, r.padinv.x), x1 = __builtin_fmaf(grid_coord<SIDE>(hix), r.inv.x, r.padinv.x);
+    const float y0 = __builtin_fmaf(grid_coord<SIDE>(loy), r.inv.y, r.padinv.y), y1 = __builtin_fmaf(grid_coord<SIDE>(hiy), r.inv.y, r.padinv.y);
+    const float z0 = __builtin_fmaf(grid_coord<SIDE>(loz), r.inv.z, r.padinv.z), z1 = __builtin_fmaf(grid_coord<SIDE>(hiz), r.inv.z, r.padinv.z);
     const float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
     const float ef = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
     *entry = en;
     return (en <= ef) & (((en <= t_hi) & (ef >= t_lo)) | nocull);
 }
-// May this ray walk the tight tree?  (E_build covers its origin, 1/d small enough that no slab
-// product overflows.)  If so the ray's padinv is replaced by -o*inv.
-__device__ __forceinline__ bool make_tight_ray(BoxRay& r, V3 extent, float tight_e) {
+// May this ray walk the tight tree?  (E_build covers its origin, 1/d small enough that no slab product
+// overflows.)  If so the ray is moved onto the tree's grid: inv becomes step/d and padinv (base - o)/d, so that
+// the slab parameter of grid index u is fma(u, inv, padinv); the sign flags keep their meaning (step > 0).
+// The exact 1/d is gone from the ray after this: the leaf-box check re-forms it (exact_box_ray).
+__device__ __forceinline__ bool make_tight_ray(BoxRay& r, V3 extent, float tight_e, const float* base, const float* step) {
     const float E = fmaxf(fmaxf(fabsf(r.o.x) + extent.x, fabsf(r.o.y) + extent.y), fabsf(r.o.z) + extent.z);
     const float big = 1e30f;
     const bool ok = (E <= tight_e) & (fabsf(r.inv.x) <= big) & (fabsf(r.inv.y) <= big) & (fabsf(r.inv.z) <= big);
-    if (ok) r.padinv = v3(-(r.o.x * r.inv.x), -(r.o.y * r.inv.y), -(r.o.z * r.inv.z));
+    if (ok) {
+        r.padinv = v3((base[0] - r.o.x) * r.inv.x, (base[1] - r.o.y) * r.inv.y, (base[2] - r.o.z) * r.inv.z);
+        r.inv = v3(step[0] * r.inv.x, step[1] * r.inv.y, step[2] * r.inv.z);
+    }
     return ok;
 }
 

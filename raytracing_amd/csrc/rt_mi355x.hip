@@ -202,7 +202,7 @@ WfLayout wf_layout(size_t n_px, size_t n0, int n_lights, int max_bounces) {
 int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st, bool noalloc = false) {
     WfArgs a;
     a.scene = r.scene;
-    if (!ctx->build_tight) a.scene.tight_root = 0u;
+    if (!ctx->build_tight) a.scene.tight = nullptr;
     std::memcpy(a.cam, r.cam, sizeof a.cam);
     a.max_bounces = r.max_bounces;
     a.width = r.width, a.height = r.height, a.local_rows = r.local_rows;
@@ -419,6 +419,7 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     const rtf::Flat& flat = prep.flat;
     const rtb::Bvh& bvh = prep.bvh;
     const rtb::Bvh& tight = prep.tight;
+    const rtb::QBvh& tight_q = prep.tight_q;  // what the GPU gets of it: 32-byte nodes (rt_bvh.h quantize)
     const std::vector<int32_t>&tri_slot_leaf = prep.tri_slot_leaf, &sphere_slot_leaf = prep.sphere_slot_leaf;
     const bool contained = prep.contained;
     const float* extent = prep.extent;
@@ -436,13 +437,13 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     const size_t tri_off = flat.nodes.size() * 2, sph_off = tri_off + (size_t)n_ts * 3;
     const size_t bvh_off = sph_off + (size_t)n_ss;
     const size_t geom_f4 = bvh_off + bvh.nodes.size() * 4;
-    const size_t all_f4 = geom_f4 + tight.nodes.size() * 4;
+    const size_t all_f4 = geom_f4 + tight_q.nodes.size() * 2;
     if (all_f4 >= (size_t)INT32_MAX / 2) return fail(ctx, RT_ERR_TOO_LARGE, "geometry image too large");
     if ((rc = ensure(ctx, ctx->geom, all_f4 * 16))) return rc;
     if ((rc = upload(ctx, ctx->tri_slot_leaf, tri_slot_leaf.data(), tri_slot_leaf.size() * 4))) return rc;
     if ((rc = upload(ctx, ctx->sphere_slot_leaf, sphere_slot_leaf.data(), sphere_slot_leaf.size() * 4))) return rc;
-    if (!tight.nodes.empty())
-        HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + geom_f4, tight.nodes.data(), tight.nodes.size() * sizeof(rtb::Node),
+    if (!tight_q.nodes.empty())
+        HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + geom_f4, tight_q.nodes.data(), tight_q.nodes.size() * sizeof(rtb::QNode),
                                hipMemcpyHostToDevice));
     if (!flat.nodes.empty())
         HIP_TRY(ctx, hipMemcpy(ctx->geom.p, flat.nodes.data(), flat.nodes.size() * 32, hipMemcpyHostToDevice));
@@ -498,7 +499,8 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
         s.root_lo[0] = root.minx, s.root_lo[1] = root.miny, s.root_lo[2] = root.minz;
         s.root_hi[0] = root.maxx, s.root_hi[1] = root.maxy, s.root_hi[2] = root.maxz;
     }
-    s.tight_root = tight.nodes.empty() ? 0u : (uint32_t)bvh.nodes.size();
+    s.tight = tight_q.nodes.empty() ? nullptr : (const uint4*)((const float4*)ctx->geom.p + geom_f4);
+    for (int k = 0; k < 3; k++) s.tight_base[k] = tight_q.base[k], s.tight_step[k] = tight_q.step[k];
     s.tight_e = tight_e;
     s.tri_slot_leaf = (const int32_t*)ctx->tri_slot_leaf.p;
     s.sphere_slot_leaf = (const int32_t*)ctx->sphere_slot_leaf.p;
@@ -522,7 +524,7 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     inf.device_bytes += (int64_t)(bvh.nodes.size() * sizeof(rtb::Node));
     inf.tight_nodes = (int64_t)tight.nodes.size();
     inf.tight_levels = tight.nodes.empty() ? 0 : tight.levels;
-    inf.device_bytes += (int64_t)(tight.nodes.size() * sizeof(rtb::Node) + (tri_slot_leaf.size() + sphere_slot_leaf.size()) * 4);
+    inf.device_bytes += (int64_t)(tight_q.nodes.size() * sizeof(rtb::QNode) + (tri_slot_leaf.size() + sphere_slot_leaf.size()) * 4);
     ctx->lds_capable = !bvh.nodes.empty() && ctx->lds_bytes <= (size_t)ctx->lds_limit;
     ctx->has_scene = true;
     ctx->scene_serial++;
@@ -548,13 +550,6 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     int rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
                           accel_len, opt, &prep, &err);
     if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
-    {  // the tight nodes follow the leaf tree's in one array: inner refs become indices of that array
-        const uint32_t base = (uint32_t)prep.bvh.nodes.size();
-        for (rtb::Node& nd : prep.tight.nodes) {
-            for (uint32_t& r : nd.ref)
-                if (!(r & rtb::LEAF)) r += base;
-        }
-    }
     if (ctx->multi) return multi_upload(ctx, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
     return upload_prepared(ctx, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
 }
@@ -610,6 +605,7 @@ int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, in
         msg = rtp::verify_tree(prep.bvh, nullptr, nullptr, nullptr);
         if (msg.empty())
             msg = rtp::verify_tree(prep.tight, &prep, (const unsigned char*)spheres, (const unsigned char*)triangles);
+        if (msg.empty()) msg = rtp::verify_quantized(prep.tight, prep.tight_q);
         if (!msg.empty()) rc = RT_ERR_DEVICE;  // an internal inconsistency, never expected
     }
     if (err && err_cap) {

@@ -28,6 +28,7 @@ struct Prepared {
     rtf::Flat flat;
     rtb::Bvh bvh;    // re-treed leaves; empty if the tree is not nested
     rtb::Bvh tight;  // per-primitive tree (inner refs relative to its own node 0); empty if not built
+    rtb::QBvh tight_q;  // the same tree as the GPU walks it: 32-byte nodes, boxes on a 16-bit grid (rt_bvh.h quantize)
     std::vector<int32_t> tri_slot_leaf, sphere_slot_leaf;  // slot -> reference leaf record (tight tree only)
     std::vector<uint8_t> tri_unbounded;                    // per triangle slot (rtf::meta_nocull)
     float extent[3] = {0, 0, 0};  // per-axis max |coordinate| of the root box
@@ -179,6 +180,9 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
         if (out->tight.levels > rtb::MAX_LEVELS) out->tight = rtb::Bvh();
     }
     lap("tight tree (SAH)");
+    out->tight_q = rtb::QBvh();
+    if (!out->tight.nodes.empty() && !rtb::quantize(out->tight, &out->tight_q)) out->tight = rtb::Bvh();
+    lap("tight tree -> 16-bit grid");
     return rtf::FLATTEN_OK;
 }
 
@@ -274,6 +278,30 @@ inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, cons
         for (uint8_t s : seen_sph)
             if (s != 1) return "sphere slot missing from the tight tree";
     }
+    return "";
+}
+
+// The 32-byte form against the tree it was made from: same refs, and every grid box contains its fp32 box
+// (empty slots stay inverted) while growing by less than 1.01 grid steps per side.
+inline std::string verify_quantized(const rtb::Bvh& t, const rtb::QBvh& q) {
+    if (t.nodes.size() != q.nodes.size()) return "quantised tree has a different node count";
+    for (size_t i = 0; i < t.nodes.size(); i++)
+        for (int side = 0; side < 2; side++) {
+            if (q.nodes[i].ref[side] != t.nodes[i].ref[side]) return "quantised tree has a different ref";
+            float lo[3], hi[3];
+            double qlo[3], qhi[3];
+            t.nodes[i].get_box(side, lo, hi);
+            q.get_box(i, side, qlo, qhi);
+            const bool empty = !(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]);
+            for (int c = 0; c < 3; c++) {
+                if (empty) {
+                    if (!(qlo[c] > qhi[c])) return "empty child slot is not inverted on the grid";
+                    continue;
+                }
+                if (!(qlo[c] <= lo[c] && qhi[c] >= hi[c])) return "grid box does not contain its fp32 box";
+                if (!(lo[c] - qlo[c] <= 1.01 * q.step[c] && qhi[c] - hi[c] <= 1.01 * q.step[c])) return "grid box looser than one step";
+            }
+        }
     return "";
 }
 

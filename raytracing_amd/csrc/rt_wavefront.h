@@ -162,7 +162,7 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
 #else
             const uint32_t k = wf_draw(head, total, cur == NONE, &exhausted);
 #endif
-            if (k != NONE && job.setup(k)) cur = job.tight ? job.a.scene.tight_root : 0u, sp = 0, lk = 0;  // a root holder
+            if (k != NONE && job.setup(k)) cur = 0u, sp = 0, lk = 0;  // the root holder of either tree
             continue;
         }
         if (n_idle == 64) {
@@ -177,23 +177,31 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
 #pragma unroll
             for (int rep = 0; rep < RT_WF_NODE_REPS; rep++)
             if (!(cur & LEAF)) {  // node step (NONE has the leaf bit)
-                const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2);
-                const uint2 refs = g.bvh_refs(cur);
                 const float th = job.t_hi();
                 float e0, e1;
-                const uint32_t r0 = refs.x, r1 = refs.y;
-                const bool nc0 = G::unbounded && rtb::ref_nocull(r0), nc1 = G::unbounded && rtb::ref_nocull(r1);
+                uint32_t r0, r1;
                 bool h0, h1;
-                // (the scalar tests on the unpacked boxes: the packed pair forms of rt_device.h cost these kernels,
-                // which run at an 80-VGPR cap, twice the spills -- Soup1M 4K 57 -> 100 ms)
-                const float4 lo0 = make_float4(q0.x, q0.z, q1.x, 0), hi0 = make_float4(q1.z, q2.x, q2.z, 0);
-                const float4 lo1 = make_float4(q0.y, q0.w, q1.y, 0), hi1 = make_float4(q1.w, q2.y, q2.w, 0);
-                if (job.tight) {  // conservative filter (rt_bvh.h build_tight)
-                    h0 = SlabHit(job.br, lo0, hi0, job.t_lo, th, &e0, nc0);
-                    h1 = SlabHit(job.br, lo1, hi1, job.t_lo, th, &e1, nc1);
+                if (job.tight) {  // conservative filter (rt_bvh.h build_tight): a 32-byte node, boxes on the 16-bit grid
+                    const uint4 q0 = g.tight_node(cur, 0), q1 = g.tight_node(cur, 1);
+                    r0 = q1.z, r1 = q1.w;
+                    const bool nc0 = G::unbounded && rtb::ref_nocull(r0), nc1 = G::unbounded && rtb::ref_nocull(r1);
+                    h0 = SlabHitQ<0>(job.br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, job.t_lo, th, &e0, nc0);
+                    h1 = SlabHitQ<1>(job.br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, job.t_lo, th, &e1, nc1);
+                    // (keeps the refs part of THIS fetch: left alone, the compiler merges the two branches' ref loads
+                    // into one load behind the branch, a second dependent memory round trip per step -- 55 -> 66 ms)
+                    asm volatile("" : "+v"(r0), "+v"(r1));
                 } else {  // the reference's test on the reference's leaf boxes
+                    const float4 q0 = g.bvh_node(cur, 0), q1 = g.bvh_node(cur, 1), q2 = g.bvh_node(cur, 2);
+                    const uint2 refs = g.bvh_refs(cur);
+                    r0 = refs.x, r1 = refs.y;
+                    const bool nc0 = G::unbounded && rtb::ref_nocull(r0), nc1 = G::unbounded && rtb::ref_nocull(r1);
+                    // (the scalar tests on the unpacked boxes: the packed pair forms cost these kernels, which run at
+                    // an 80-VGPR cap, twice the spills -- Soup1M 4K 57 -> 100 ms)
+                    const float4 lo0 = make_float4(q0.x, q0.z, q1.x, 0), hi0 = make_float4(q1.z, q2.x, q2.z, 0);
+                    const float4 lo1 = make_float4(q0.y, q0.w, q1.y, 0), hi1 = make_float4(q1.w, q2.y, q2.w, 0);
                     h0 = IntersectBoundingBoxCull(job.br, lo0, hi0, job.t_lo, th, &e0, nc0);
                     h1 = IntersectBoundingBoxCull(job.br, lo1, hi1, job.t_lo, th, &e1, nc1);
+                    asm volatile("" : "+v"(r0), "+v"(r1));
                 }
                 h0 &= r0 != LEAF, h1 &= r1 != LEAF;
                 if (h0 & h1) {
@@ -255,7 +263,8 @@ struct WfClosestJob {
     __device__ __forceinline__ bool leaf_passes(const int32_t* slot_leaf, int slot) const {
         if (!tight) return true;
         const int leaf = slot_leaf[slot];
-        return IntersectBoundingBox(br, g.node_lo(leaf), g.node_hi(leaf));
+        // (the tight ray lives on the tree's grid: the reference's test takes the ray as the shader forms it)
+        return IntersectBoundingBox(make_box_ray(o, d), g.node_lo(leaf), g.node_hi(leaf));
     }
     __device__ __forceinline__ void sphere(int slot) {
         const float4 s = g.sphere(slot);
@@ -299,7 +308,7 @@ struct WfClosestJob {
         }
         tight = false;
         if (ray_is_regular(br) && S.n_nodes > 0) {
-            tight = S.tight_root != 0u && make_tight_ray(br, v3(S.extent[0], S.extent[1], S.extent[2]), S.tight_e);
+            tight = S.tight != nullptr && make_tight_ray(br, v3(S.extent[0], S.extent[1], S.extent[2]), S.tight_e, S.tight_base, S.tight_step);
             return true;
         }
         // zero direction component etc.: the exact tree, exhaustively (rare)
@@ -323,7 +332,8 @@ struct WfClosestJob {
 #endif
 template <bool UNB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_PER_EU, 8))) void k_wf_closest(const WfArgs a) {
-    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
+    GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
+    g.tight = a.scene.tight;
     WfClosestJob<GeomBvhT<UNB>> job{a, g, a.iter == 0 ? 0.0f : RT_EPSILON};
     wf_run(g, a.counters + 4 * a.iter + 1, wf_active_count(a), job);
 }
@@ -353,7 +363,8 @@ struct WfAnyJob {
     __device__ __forceinline__ bool leaf_passes(const int32_t* slot_leaf, int slot) const {
         if (!tight) return true;
         const int leaf = slot_leaf[slot];
-        return IntersectBoundingBox(br, g.node_lo(leaf), g.node_hi(leaf));
+        // (the tight ray lives on the tree's grid: the reference's test takes the ray as the shader forms it)
+        return IntersectBoundingBox(make_box_ray(o, d), g.node_lo(leaf), g.node_hi(leaf));
     }
     __device__ __forceinline__ void sphere(int slot) {
         const float4 s = g.sphere(slot);
@@ -413,7 +424,7 @@ struct WfAnyJob {
         }
         tight = false;
         if (!blocked && ray_is_regular(br) && S.n_nodes > 0) {
-            tight = S.tight_root != 0u && make_tight_ray(br, v3(S.extent[0], S.extent[1], S.extent[2]), S.tight_e);
+            tight = S.tight != nullptr && make_tight_ray(br, v3(S.extent[0], S.extent[1], S.extent[2]), S.tight_e, S.tight_base, S.tight_step);
             return true;
         }
         if (!blocked)
@@ -434,7 +445,8 @@ struct WfAnyJob {
 
 template <bool UNB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_PER_EU, 8))) void k_wf_any(const WfArgs a) {
-    const GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
+    GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, (int)(threadIdx.x & 63)};
+    g.tight = a.scene.tight;
     const uint32_t n_active = wf_active_count(a);
     WfAnyJob<GeomBvhT<UNB>> job{a, g, n_active, RT_EPSILON};
     // the last group of 64 paths is padded: setup() skips j >= n_active
