@@ -274,9 +274,12 @@ inline void build(const rtf::Flat& flat, Bvh* out) {
 //   triangle  IntersectTriangle intersects the plane through A with the STORED normal N and accepts
 //             points X whose projection along N falls inside ABC, i.e. X in the triangle A B' C'
 //             (B', C' = B, C projected along N onto that plane; equal to B, C for an exact normal).
-//             The accepted X_c = o + t_c d misses that plane by <= eps(5|A-o| + 3 t_c) and the edges
-//             by a few eps * scale: < 32 eps E with E >= |o_k| + |coordinate| on every axis.  The box
-//             is bbox(A, B', C') grown by pad_tri = 2^-14 E_build (1000 eps E_build).
+//             The accepted X_c = o + t_c d misses that plane by <= eps(5|A-o| + 3 t_c): < 32 eps E with
+//             E >= |o_k| + |coordinate| on every axis.  An edge test is off by up to ~4 eps |edge| at the
+//             edge's far end, so where two edges meet at a small angle the accepted region reaches past the
+//             vertex: by <= 8 eps L / sin(angle), L = longest edge (sliver_reach below).  The box is
+//             bbox(A, B', C') grown by pad_tri = 2^-14 E_build (1000 eps E_build) PLUS that reach; triangles
+//             whose reach exceeds max_extent / 512 are treated as unbounded (rt_scene_prep.h).
 //   sphere    the computed root differs from an exact root (or, when rounding created the root, from
 //             the closest approach) by <= sqrt(68 eps)/2 |o-c|, and the closest approach misses the
 //             sphere by at most the same amount: X_c is within 2.0e-3 |o-c| <= 3.5e-3 E of the
@@ -294,6 +297,32 @@ inline void build(const rtf::Flat& flat, Bvh* out) {
 // regular direction may use this tree; the others take the leaf-box tree above.  Inner boxes are
 // unions of the padded leaf boxes.
 // ------------------------------------------------------------------------------------------
+// Shape of a triangle record (TriangleStruct: A|_ B|_ C|_ N|_) as the edge tests see it: L = longest edge,
+// ratio = (area of A B' C' doubled) / L^2 ~ the smallest angle for a sliver.  False if the stored normal is zero
+// or NaN (then the triangle is never hit) -- ratio may still be 0 or NaN for collinear vertices.
+inline bool triangle_shape(const float* rec, double* ratio, double* longest) {
+    const float* n = rec + 12;
+    const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+    if (!(nn == nn) || !(nn > 0)) return false;
+    const double e1[3] = {(double)rec[4] - rec[0], (double)rec[5] - rec[1], (double)rec[6] - rec[2]};
+    const double e2[3] = {(double)rec[8] - rec[0], (double)rec[9] - rec[1], (double)rec[10] - rec[2]};
+    const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
+    const double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double area2 = std::fabs(cr[0] * n[0] + cr[1] * n[1] + cr[2] * n[2]) / nn;
+    const double len2 = std::max({e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2],
+                                  e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]});
+    *ratio = area2 / len2, *longest = std::sqrt(len2);
+    return true;
+}
+// How far past a vertex the rounding of the edge tests lets an accepted hit point lie (see the proof above);
+// 0 for a triangle that is never hit, +inf for collinear vertices.
+inline double sliver_reach(const float* rec) {
+    double ratio, longest;
+    if (!triangle_shape(rec, &ratio, &longest)) return 0.0;
+    if (!(ratio > 0)) return INFINITY;
+    return 8.0 * 5.9604644775390625e-8 * longest / ratio;
+}
+
 struct TightInput {
     const unsigned char* tris = nullptr;     // TriangleStruct records, 96 B: A|_ B|_ C|_ N|_ ...
     const unsigned char* spheres = nullptr;  // SphereStruct records, 48 B: center, radius
@@ -357,7 +386,7 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
                         lo[c] = std::min(lo[c], x), hi[c] = std::max(hi[c], x);
                     }
                 }
-                pad = in.pad_tri;
+                pad = in.pad_tri + sliver_reach(r);  // (bounded: <= max_extent / 512 for every triangle that gets here)
             } else {
                 (*sphere_slot_leaf)[slot] = (int32_t)ni;
                 const float* r = (const float*)(in.spheres + (size_t)flat.sphere_slot_id[slot] * 48);

@@ -233,7 +233,8 @@ __device__ __forceinline__ bool IntersectBoundingBox(const BoxRay& r, float4 lo,
 // inside the node's box grown by `pad` on every side, hence t_c lies inside the slab interval of
 // the grown box, [max_i(tnear_i - pad*|inv_i|), min_i(tfar_i + pad*|inv_i|)].  For a triangle the
 // off-plane error of X_c is a few ulps of the scene scale E and its in-plane position passed the
-// edge tests; for a sphere the error of t_c is bounded by sqrt(8*4*eps)*(|o-c|+r) < 2.8e-3*E (the
+// edge tests (rounded: up to rtb::sliver_reach <= max_extent/512 past a sharp vertex, or the upload
+// marks the triangle unbounded and its subtree is never culled); for a sphere the error of t_c is bounded by sqrt(8*4*eps)*(|o-c|+r) < 2.8e-3*E (the
 // worst case is a grazing ray, discriminant ~ 0).  pad = E/128 = 7.8e-3*E covers both.  NaN slab
 // values (zero direction components) make every comparison false: no cull, as in the reference.
 __device__ __forceinline__ bool IntersectBoundingBoxCull(const BoxRay& r, float4 lo, float4 hi, float t_lo,

@@ -43,19 +43,16 @@ struct Prepared {
 // for vertices that are collinear or coincident as seen along that normal this is a whole line or the
 // whole plane, wherever the ray passes the leaf's box test (which has no distance bound).  Width/length
 // below 1e-5 is within rounding of that case (the reference's table model has 19 such triangles).
-// A NaN or zero normal never yields a hit and is not "unbounded".
-inline bool triangle_is_unbounded(const float* rec) {
-    const float* n = rec + 12;
-    const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
-    if (!(nn == nn) || !(nn > 0)) return false;
-    const double e1[3] = {(double)rec[4] - rec[0], (double)rec[5] - rec[1], (double)rec[6] - rec[2]};
-    const double e2[3] = {(double)rec[8] - rec[0], (double)rec[9] - rec[1], (double)rec[10] - rec[2]};
-    const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
-    const double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-    const double area2 = std::fabs(cr[0] * n[0] + cr[1] * n[1] + cr[2] * n[2]) / nn;
-    const double len2 = std::max({e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2],
-                                  e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]});
-    return !(area2 > 0) || !(area2 >= 1e-5 * len2);
+// The same holds, to a degree, for any sliver: rounding lets the edge tests accept points up to
+// rtb::sliver_reach past a sharp vertex.  The distance cull (pad E/128) and the tight boxes (which add the reach
+// to their pad) assume hits near the primitive, so a triangle whose reach exceeds max_extent / 512 -- a quarter
+// of the cull's pad; a sliver with angle below 2.4e-4 * longest edge / max_extent -- is treated as unbounded
+// too.  A NaN or zero normal never yields a hit and is not "unbounded".
+inline bool triangle_is_unbounded(const float* rec, float max_extent) {
+    double ratio, longest;
+    if (!rtb::triangle_shape(rec, &ratio, &longest)) return false;
+    if (!(ratio > 0) || !(ratio >= 1e-5)) return true;
+    return !(rtb::sliver_reach(rec) <= (double)max_extent * (1.0 / 512.0));
 }
 
 // Distance cull precondition: boxes nested, every primitive inside its leaf box (within a slack far
@@ -64,7 +61,7 @@ inline bool triangle_is_unbounded(const float* rec) {
 // Leaf records are independent: the upload runs this over node ranges on up to 16 threads (a million primitives
 // take 0.17 s on one core).
 inline bool check_containment_range(const rtf::Flat& flat, const unsigned char* spheres, const unsigned char* triangles,
-                                    float slack, size_t n0, size_t n1, std::vector<uint8_t>* tri_unbounded,
+                                    float slack, float max_extent, size_t n0, size_t n1, std::vector<uint8_t>* tri_unbounded,
                                     std::vector<int32_t>* unbounded_leaves) {
     for (size_t ni = n0; ni < n1; ni++) {
         const rtf::FlatNode& fn = flat.nodes[ni];
@@ -97,7 +94,7 @@ inline bool check_containment_range(const rtf::Flat& flat, const unsigned char* 
                                              ((double)rec[4 * v + 2] - rec[2]) * n[2]);
                 if (!(off <= 4.0 * slack * nn)) return false;
             }
-            if (triangle_is_unbounded(rec)) {
+            if (triangle_is_unbounded(rec, max_extent)) {
                 (*tri_unbounded)[first + k] = 1;  // slots of different leaves: no two threads write the same byte
                 unbounded_leaves->push_back((int32_t)ni);
             }
@@ -109,16 +106,17 @@ inline bool check_containment(const rtf::Flat& flat, const unsigned char* sphere
                               const float extent[3], std::vector<uint8_t>* tri_unbounded,
                               std::vector<int32_t>* unbounded_leaves) {
     if (!flat.nested) return false;
-    const float slack = std::fmax(extent[0], std::fmax(extent[1], extent[2])) * (1.0f / 4096.0f);
+    const float max_extent = std::fmax(extent[0], std::fmax(extent[1], extent[2]));
+    const float slack = max_extent * (1.0f / 4096.0f);
     const size_t n = flat.nodes.size();
     const int n_threads = n < (1u << 16) ? 1 : (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
-    if (n_threads == 1) return check_containment_range(flat, spheres, triangles, slack, 0, n, tri_unbounded, unbounded_leaves);
+    if (n_threads == 1) return check_containment_range(flat, spheres, triangles, slack, max_extent, 0, n, tri_unbounded, unbounded_leaves);
     std::vector<std::vector<int32_t>> found(n_threads);
     std::vector<char> ok(n_threads, 1);
     std::vector<std::thread> pool;
     for (int t = 0; t < n_threads; t++)
         pool.emplace_back([&, t] {
-            ok[t] = check_containment_range(flat, spheres, triangles, slack, n * t / n_threads, n * (t + 1) / n_threads,
+            ok[t] = check_containment_range(flat, spheres, triangles, slack, max_extent, n * t / n_threads, n * (t + 1) / n_threads,
                                             tri_unbounded, &found[t]) ? 1 : 0;
         });
     for (std::thread& th : pool) th.join();
@@ -252,8 +250,8 @@ inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, cons
                     const bool project = nn > 0 && sc == sc;
                     for (int c = 0; c < 3; c++) {
                         const double x = project ? (double)rec[4 * v + c] - sc * n[c] : (double)rec[4 * v + c];
-                        if (!(x - tight_of->pad_tri >= td.lo[c] - 1e-6 * std::fabs(td.lo[c]) &&
-                              x + tight_of->pad_tri <= td.hi[c] + 1e-6 * std::fabs(td.hi[c])))
+                        const double pad = tight_of->pad_tri + rtb::sliver_reach(rec);
+                        if (!(x - pad >= td.lo[c] - 1e-6 * std::fabs(td.lo[c]) && x + pad <= td.hi[c] + 1e-6 * std::fabs(td.hi[c])))
                             return "triangle region sticks out of its padded tight box";
                     }
                 }

@@ -21,7 +21,7 @@ def test_reference_scenes_pass_every_precondition(name, params, scene_of):
     b = info["n_sphere_slots"] + info["unbounded_triangles"]
     assert info["tight_nodes"] == 1 + max(a - 1, 0) + max(b - 1, 0)
     assert 0 < info["tight_levels"] <= 32 and 0 < info["bvh_levels"] <= 32
-    assert info["unbounded_triangles"] == (19 if name == "TeapotTable" else 0)
+    assert info["unbounded_triangles"] == (21 if name == "TeapotTable" else 0)   # 19 collinear + 2 long slivers
     small = check_scene(sc)                             # default threshold (RT_OPTION_TIGHT_MIN_NODES): only large scenes
     assert (small["tight_nodes"] > 0) == (small["n_nodes"] >= 1000)
 
@@ -66,6 +66,37 @@ def test_degenerate_triangles_are_marked_not_refused(scene_of):
     odd = Scene(sc.spheresData, sc.planesData, tri, accel, sc.lightsData, sc.cameraData)
     info = check_scene(odd, 0)
     assert info["flags"] == 3 and info["unbounded_triangles"] == 2 and info["tight_nodes"] > 0
+
+
+def _with_slivers(sc, specs):
+    """Replace the first len(specs) finite-normal triangles by slivers A, A + L*u, A + L*u/2 + L*angle*v (u, v
+    unit vectors in the plane of the original triangle); returns the scene and the indices."""
+    tri = sc.trianglesData.copy()
+    idx = np.nonzero(np.isfinite(tri["Normal"]).all(axis=1))[0][:len(specs)]
+    for i, (L, angle) in zip(idx, specs):
+        a = tri["PointA"][i].astype(np.float64)
+        n = tri["Normal"][i].astype(np.float64)
+        u = np.cross(n, [0.3, 0.5, 0.8]); u /= np.linalg.norm(u)
+        v = np.cross(n, u)
+        tri["PointB"][i] = (a + L * u).astype(np.float32)
+        tri["PointC"][i] = (a + 0.5 * L * u + L * angle * v).astype(np.float32)
+    accel = host.accel_from_structs(sc.spheresData, tri)
+    return Scene(sc.spheresData, sc.planesData, tri, accel, sc.lightsData, sc.cameraData), idx
+
+
+def test_long_slivers_count_as_unbounded(scene_of):
+    """Rounding lets the edge tests accept points up to ~8 eps * longest edge / angle past a sharp vertex.  The
+    tight boxes add that reach to their pad; where it would exceed max_extent / 512 (a quarter of the distance
+    cull's pad) the triangle is marked unbounded like a collinear one: never culled, walked by a line test."""
+    sc = scene_of("TeapotScene")
+    # (longest edge, angle): short slivers and blunt triangles stay bounded; a long edge with a tiny angle does not
+    specs = [(0.5, 1e-3), (5.0, 2e-2), (0.01, 2e-5), (5.0, 2e-5), (30.0, 1e-4)]
+    odd, idx = _with_slivers(sc, specs)
+    info = check_scene(odd, 0)                    # (also runs the library's self-check of the padded tight boxes)
+    assert info["flags"] == 3 and info["tight_nodes"] > 0
+    extent = max(abs(float(x)) for x in odd.AccelerationStructureData[0:6])
+    expect = sum(1 for L, ang in specs if 8 * 2.0 ** -24 * L / (ang * 0.999) > extent / 512)
+    assert expect == 2 and info["unbounded_triangles"] == expect
 
 
 def test_malformed_arrays_are_refused(scene_of):
