@@ -51,6 +51,9 @@ struct DevScene {
     int32_t leaf_levels; // stack entries per lane of the megakernels, which walk the re-treed leaves only
     int32_t bvh_off;
     float root_lo[3], root_hi[3];  // the reference tree's root box (host side: tile priority)
+    // sphere around the root box for misses_scene: centre, and the square of (half diagonal + 1e-5 * (|centre|_1 +
+    // half diagonal)); +inf = never skip (no tree, or coordinates beyond 1e17)
+    float bound_c[3], bound_r2;
     // tight per-primitive tree (rt_bvh.h build_tight), stored behind the image as 32-byte nodes with boxes on a
     // 16-bit grid (rtb::QNode: coordinate = tight_base + index * tight_step); node 0 is its root holder; null =
     // not built / not used.  Only rays with max_k(|o_k| + extent_k) <= tight_e may walk it; *_slot_leaf map a
@@ -319,6 +322,25 @@ __device__ __forceinline__ float IntersectTriangleWindowed(V3 o, V3 d, V3 A, V3 
     const bool outside = (dot(cross(B - A, X - A), N) < 0) | (dot(cross(C - B, X - B), N) < 0) |
                          (dot(cross(A - C, X - C), N) < 0);
     return outside ? -1.0f : t;
+}
+
+// Does this ray certainly have no candidates in the tree?  A division-free test in front of the per-ray set-up
+// of the per-lane kernels (three correctly rounded 1/d, the cull pads, the root box test: ~70 VALU instructions,
+// and most rays of a scene like the teapot's never come near the model).  True only if the ray is regular
+// (every |d_k| >= 1e-30, origin within 1e17) and its LINE passes the sphere around the root box at more than
+//     sqrt(R'^2 + 1e-4 |c - o|^2),     R' = R + 1e-5 (|c|_1 + R),  R = half diagonal of the root box.
+// Why that is safe: if the reference's box test (raytracer_fs.glsl:134-161; a line test, no distance bound)
+// accepts the root box for a regular ray, its three computed slab intervals share a parameter t*, and each
+// computed bound is off by <= 2 eps |bound - o_k| in space, so the point o + t* d lies within 2 eps E of the box
+// on every axis, E = |o| + extent: the line passes the box at less than 4 eps E <= 2.4e-7 (|c - o| + |c| + extent).
+// The margins above exceed that by two orders of magnitude (R' - R covers the |c| + extent part, the 1e-4 term
+// the |c - o| part; the test's own rounding is ~1e-6 of its terms).  The root box holds every leaf box (nested
+// trees only reach the per-lane kernels), so no leaf is accepted either.  NaNs make the comparison false.
+__device__ __forceinline__ bool misses_scene(const DevScene& S, V3 o, V3 d) {
+    const V3 oc = v3(S.bound_c[0] - o.x, S.bound_c[1] - o.y, S.bound_c[2] - o.z);
+    const float q = dot(oc, oc), b = dot(oc, d), dd = dot(d, d);
+    const float dmin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    return (dmin >= 1e-30f) & (q <= 1e34f) & (dd <= 1e30f) & ((q - S.bound_r2) * dd - b * b > 1e-4f * q * dd);
 }
 
 // A ray whose origin and 1/d are finite: the precondition of the re-treed traversal (rt_bvh.h).

@@ -185,10 +185,14 @@ __device__ __forceinline__ void bvh_walk(const G& g, const BoxRay& br, bool aliv
 // step); it tests nothing and returns "no hit".
 template <bool REF, class G>
 __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V3 o, V3 d, float minDistance,
-                                                uint32_t* cnt, bool alive = true) {
+                                                uint32_t* cnt, bool alive = true, bool try_skip = true) {
     Closest h = fresh_closest();
-    const BoxRay br = REF ? make_box_ray(o, d)
-                          : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
+    // (per-lane BVH kernels form the ray's box parameters only if the ray can meet the tree at all, see below)
+    BoxRay br;
+    if (REF)
+        br = make_box_ray(o, d);
+    else if (!is_bvh<G>::value)
+        br = make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
     // fast kernels: distance only per test; the normal IntersectSphere forms at the accepted t
     // (raytracer_fs.glsl:106-111) is computed once for the winner, after the walk (same expression, same bits)
     auto sphere = [&](int slot) {
@@ -242,15 +246,19 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
             if (closer(t, 2, slot, minDistance, h)) h.t = t, h.kind = 2, h.index = slot;
         };
         if constexpr (is_bvh<G>::value) {
-            const bool regular = ray_is_regular(br);
-            if (!regular && alive) {  // zero direction component etc.: the exact tree, exhaustively (rare)
-                auto tri_b = [&](int slot) {
-                    tri_fast(slot);
-                    return false;
-                };
-                walk<false>(g, S.n_nodes, br, 3, false, nullptr, sphere, tri_b);
+            // a ray that certainly misses the tree's root box has no candidates (misses_scene): no 1/d, no box test
+            if (alive && !(try_skip && misses_scene(S, o, d))) {
+                br = make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
+                const bool regular = ray_is_regular(br);
+                if (!regular) {  // zero direction component etc.: the exact tree, exhaustively (rare)
+                    auto tri_b = [&](int slot) {
+                        tri_fast(slot);
+                        return false;
+                    };
+                    walk<false>(g, S.n_nodes, br, 3, false, nullptr, sphere, tri_b);
+                }
+                bvh_walk(g, br, regular, minDistance, [&] { return h.t; }, sphere, tri_fast, [] { return false; });
             }
-            bvh_walk(g, br, regular && alive, minDistance, [&] { return h.t; }, sphere, tri_fast, [] { return false; });
         } else {
             wave_walk(g, S.n_nodes, br, alive, minDistance, [&] { return h.t; }, sphere, tri_fast,
                       [] { return false; });
@@ -269,9 +277,12 @@ __device__ __forceinline__ Closest find_closest(const DevScene& S, const G& g, V
 // alive = false (fast kernels only): the lane has no ray; nothing is tested, the result is meaningless.
 template <bool REF, class G>
 __device__ __forceinline__ bool object_in_way(const DevScene& S, const G& g, float distanceToLight, V3 o, V3 d,
-                                              uint32_t* cnt, bool alive = true) {
-    const BoxRay br = REF ? make_box_ray(o, d)
-                          : make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
+                                              uint32_t* cnt, bool alive = true, bool try_skip = true) {
+    BoxRay br;  // (per-lane BVH kernels: formed only for rays that can meet the tree, as in find_closest)
+    if (REF)
+        br = make_box_ray(o, d);
+    else if (!is_bvh<G>::value)
+        br = make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
     bool blocked = false;
     auto in_range = [&](float t) { return t > RT_EPSILON && t < distanceToLight; };
     auto tri = [&](int slot) {
@@ -320,20 +331,23 @@ __device__ __forceinline__ bool object_in_way(const DevScene& S, const G& g, flo
             if (in_range(IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N, in_range))) blocked = true;
         };
         if constexpr (is_bvh<G>::value) {
-            const bool regular = ray_is_regular(br);
-            if (!regular && !blocked) {
-                auto sphere_b = [&](int slot) {
-                    sphere(slot);
-                    return blocked;
-                };
-                auto tri_b = [&](int slot) {
-                    tri_any(slot);
-                    return blocked;
-                };
-                walk<false>(g, S.n_nodes, br, 3, false, nullptr, sphere_b, tri_b);
+            if (!blocked && !(try_skip && misses_scene(S, o, d))) {
+                br = make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
+                const bool regular = ray_is_regular(br);
+                if (!regular) {
+                    auto sphere_b = [&](int slot) {
+                        sphere(slot);
+                        return blocked;
+                    };
+                    auto tri_b = [&](int slot) {
+                        tri_any(slot);
+                        return blocked;
+                    };
+                    walk<false>(g, S.n_nodes, br, 3, false, nullptr, sphere_b, tri_b);
+                }
+                bvh_walk(g, br, regular && !blocked, RT_EPSILON, [&] { return distanceToLight; }, sphere, tri_any,
+                         [&] { return blocked; });
             }
-            bvh_walk(g, br, regular && !blocked, RT_EPSILON, [&] { return distanceToLight; }, sphere, tri_any,
-                     [&] { return blocked; });
         } else {
             wave_walk(g, S.n_nodes, br, !blocked, RT_EPSILON, [&] { return distanceToLight; }, sphere, tri_any,
                       [&] { return blocked; });
@@ -445,6 +459,11 @@ __device__ __forceinline__ V3 primary_direction(const float* cam, float px, floa
                      rayOrigin);
 }
 
+#ifndef RT_SKIP_SEGMENTS
+#define RT_SKIP_SEGMENTS 2  // path segments (primary = 0) whose rays try misses_scene first: the rays of a tile are
+                            // still near-parallel there, so whole waves skip the set-up; after more bounces some lane
+                            // nearly always needs the walk and the test is only overhead
+#endif
 template <bool REF, class G>
 __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, const float* cam, float px, float py,
                                                 int maxBounces, uint32_t* cnt) {
@@ -469,7 +488,7 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
                 const bool zero = light_term_is_zero(sf, true, rayDirection, lr);
                 if (REF && zero) cnt[C_ZERO_TERM]++;  // the reference traces it; counted for rays_traced (bench)
                 if (!REF && zero) return true;
-                return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt);
+                return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt, true, bounces < RT_SKIP_SEGMENTS);
             });
             finalColor = finalColor + combined * mult;
         }
@@ -477,7 +496,7 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
         const V3 refl = mirror_direction(sf, rayDirection);
         rayOrigin = hitPos;
         rayDirection = refl;
-        h = find_closest<REF>(S, g, rayOrigin, rayDirection, RT_EPSILON, cnt);
+        h = find_closest<REF>(S, g, rayOrigin, rayDirection, RT_EPSILON, cnt, true, bounces + 1 < RT_SKIP_SEGMENTS);
         sf = (h.kind != 3) ? resolve_surface(S, h) : no_surface();
         bounces++;
     }
@@ -492,7 +511,7 @@ __device__ __forceinline__ PixelOut shade_pixel(const DevScene& S, const G& g, c
         const bool zero = light_term_is_zero(sf, false, rayDirection, lr);
         if (REF && zero) cnt[C_ZERO_TERM]++;
         if (!REF && zero) return true;
-        return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt);
+        return object_in_way<REF>(S, g, lr.dist, hitPos, lr.L, cnt, true, bounces < RT_SKIP_SEGMENTS);
     });
     out.rgb = finalColor + combined * mult;
     return out;
@@ -836,7 +855,8 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 // ---- large scenes: per-lane ordered traversal of the re-treed leaves, stacks in LDS ----------------
 // Same pixel mapping as k_render; dynamic LDS = BLOCK_WAVES * 64 lanes * leaf_levels dwords.
 #ifndef RT_BVH_WAVES_PER_EU
-#define RT_BVH_WAVES_PER_EU 3
+#define RT_BVH_WAVES_PER_EU 4  // 128 VGPRs: left to itself the kernel takes 131 and loses the fourth wave per SIMD
+                               // (teapot 4K 0.58 -> 0.65 ms)
 #endif
 // UNB: see GeomBvhT.  COOP: the shadow rays of a bounce are regrouped over the lanes of the wave (coop_shadows);
 // dynamic LDS then also holds COOP_DWORDS per wave behind the stacks.

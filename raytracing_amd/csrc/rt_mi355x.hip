@@ -499,6 +499,18 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
         s.root_lo[0] = root.minx, s.root_lo[1] = root.miny, s.root_lo[2] = root.minz;
         s.root_hi[0] = root.maxx, s.root_hi[1] = root.maxy, s.root_hi[2] = root.maxz;
     }
+    {  // bounding sphere of the root box (rt_device.h misses_scene)
+        double c[3], r2 = 0, c1 = 0;
+        for (int k = 0; k < 3; k++) {
+            c[k] = 0.5 * ((double)s.root_lo[k] + s.root_hi[k]);
+            const double h = 0.5 * ((double)s.root_hi[k] - s.root_lo[k]);
+            r2 += h * h, c1 += std::fabs(c[k]);
+            s.bound_c[k] = (float)c[k];
+        }
+        const double R = std::sqrt(r2), Rp = R + 1e-5 * (c1 + R) + 1e-30;
+        const bool usable = !flat.nodes.empty() && std::isfinite(R) && std::isfinite(c1) && c1 + R <= 1e17;
+        s.bound_r2 = usable ? std::nextafterf((float)(Rp * Rp), INFINITY) : INFINITY;
+    }
     s.tight = tight_q.nodes.empty() ? nullptr : (const uint4*)((const float4*)ctx->geom.p + geom_f4);
     for (int k = 0; k < 3; k++) s.tight_base[k] = tight_q.base[k], s.tight_step[k] = tight_q.step[k];
     s.tight_e = tight_e;

@@ -334,6 +334,47 @@ def test_slivers_keep_every_traversal_exact(rt_mode, scene_of):
         assert_frame_matches(out, ref, "slivers " + label)
 
 
+@pytest.mark.parametrize("shift", [(0.0, 0.0, 0.0), (3000.0, 700.0, -5000.0)], ids=["at-origin", "far-from-origin"])
+def test_rays_that_graze_the_root_box(shift, rt_mode, scene_of):
+    """The per-lane kernels skip a ray's traversal set-up when its line certainly misses a sphere around the root
+    box (rt_device.h misses_scene).  Cameras zoomed onto the silhouette of the root box -- corners, edges, from
+    near and far -- and the same scene moved far from the world origin (a small box at large coordinates: the
+    margins scale with the coordinates) must reproduce the oracle in every traversal."""
+    from raytracing_amd import host
+    rt = rt_mode
+    sc = scene_of("TeapotScene")
+    tri = sc.trianglesData.copy()
+    sh = np.array(shift, dtype=np.float32)
+    for k in ("PointA", "PointB", "PointC"):
+        tri[k] = tri[k] + sh
+    accel = host.accel_from_structs(sc.spheresData, tri)
+    lights = np.asarray(sc.lightsData, dtype=np.float32).copy().reshape(-1, 6)
+    lights[:, 0:3] += sh
+    moved = Scene(sc.spheresData, sc.planesData[:0], tri, accel, lights.reshape(-1), sc.cameraData)
+    # the vertices that define the root box lie ON its faces: look at each along a direction nearly inside that face
+    pts = np.concatenate([tri["PointA"], tri["PointB"], tri["PointC"]]).astype(np.float64)
+    size = np.linalg.norm(pts.max(0) - pts.min(0))
+    seen = 0
+    for axis in range(3):
+        for sign, dist, fov in ((1, 2.0, 0.03), (-1, 60.0, 0.001)):
+            v = pts[np.argmax(sign * pts[:, axis])]
+            along = np.array([0.55, 0.33, -0.77])
+            along[axis] = 0.004 * sign                      # 0.2 degrees off the face
+            eye = v + dist * size * along / np.linalg.norm(along)
+            fwd = (v - eye) / np.linalg.norm(v - eye)
+            right = np.cross([0.0, 1.0, 0.0], fwd)
+            right /= np.linalg.norm(right)
+            cam = host.camera_pack(eye.tolist(), fwd.tolist(), right.tolist(), 1.0, fov * 1.6, fov * 0.9, 96, 54)
+            ref = oracle_render(moved, cam, 1, threads=16)
+            hit = (ref["primary_id"] >= 0).mean()
+            seen += 0.0 < hit < 1.0                             # the model's silhouette crosses the frame
+            for mode, label in MODES:
+                _set_mode(rt, mode)
+                out = _render(rt, moved, cam, 1)
+                assert_frame_matches(out, ref, f"grazing the {'+' if sign > 0 else '-'}{'xyz'[axis]} face {label}")
+    assert seen >= 4
+
+
 def test_the_table_models_collinear_triangles_are_marked(rt_mode, scene_of):
     rt = rt_mode
     rt.SendPrimitivesToShader(scene_of("TeapotTable"))
