@@ -127,12 +127,16 @@ def device_stats(rt, torch, cam, depth):
     return {k: int(v[i]) for i, k in enumerate(N.STATS_FIELDS)}
 
 
+TUNE_FRAMES = 12  # renders after which the library's kernel choice by measurement is final (rt_mi355x.hip tune_begin)
+
+
 def time_single(rt, torch, cam, depth, width, height, steps, warmup):
     """ms per frame of the fast kernel, device-resident RGBA8 output, HIP events on the launch stream.
-    (>= 5 warm-up frames: AUTO decides between its two kernels over the first four frames of a mid-sized scene.)"""
+    (>= TUNE_FRAMES warm-up frames: the library times its candidate kernels over the first frames of a (scene, size,
+    bounces) -- three frames each for up to three candidates -- and keeps the fastest.)"""
     out = torch.empty((height, width, 4), dtype=torch.uint8, device="cuda")
     s = torch.cuda.current_stream()
-    for _ in range(max(warmup, 5)):
+    for _ in range(max(warmup, TUNE_FRAMES)):
         rt.render_device(cam, depth, rgba8=out.data_ptr(), stream=s.cuda_stream)
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -402,7 +406,7 @@ def main():
     if bufs[0].staged and rank == 0:
         print(f"bench: backend {backend} cannot move device tensors in this collective; staging through host memory "
               f"(rehearsal only)", file=sys.stderr)
-    for _ in range(6):  # AUTO settles on a kernel for this (scene, local frame size, bounces) before anything is timed
+    for _ in range(TUNE_FRAMES):  # the library settles on a kernel for this (scene, local frame size, bounces) before anything is timed
         bufs[0].render(cams, depth)
         torch.cuda.synchronize()
 

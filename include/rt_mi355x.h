@@ -101,12 +101,13 @@ enum {
     RT_OPTION_TIGHT_TREE = 4, /* 1 (default): uploads of scenes with at least RT_OPTION_TIGHT_MIN_NODES node records
                                 whose primitives were verified to sit inside their leaf boxes also build a
                                 per-primitive tree that the staged pipeline walks with a cheap conservative box
-                                test, as a filter in front of the reference's leaf-box rule (64 B per primitive,
-                                ~0.25 s of host time per million); 0: neither built nor used */
+                                test, as a filter in front of the reference's leaf-box rule (32 B per primitive:
+                                child boxes on a 16-bit grid; ~0.25 s of host time per million); 0: neither built
+                                nor used */
     RT_OPTION_WAVEFRONT_MIN_NODES = 5, /* scenes with at least this many flattened node records (default 1000) are
-                                candidates for RT_TRAVERSAL_WAVEFRONT under AUTO: the first two renders of a (scene,
-                                frame size, bounces) use the megakernel, the next two the staged pipeline (the second
-                                of each pair is timed), later ones use the faster (size alone does not tell a triangle
+                                candidates for RT_TRAVERSAL_WAVEFRONT under AUTO: the first renders of a (scene, frame
+                                size, bounces) time the candidate kernels -- three frames each, a warm-up and two
+                                between events -- and later ones use the fastest (size alone does not tell a triangle
                                 soup from a field of meshes); from 100000 nodes on AUTO takes the staged pipeline
                                 without asking */
     RT_OPTION_TIGHT_MIN_NODES = 6, /* scenes with fewer flattened node records get no tight tree (default 1000; only
@@ -114,9 +115,11 @@ enum {
     RT_OPTION_COOP_SHADOWS = 7 /* 1: the BVH megakernel keeps the lanes of a wave in step through the mirror loop and,
                                 in bounces where fewer than 40 lanes need shadow rays, regroups those rays over all
                                 64 lanes (ballot compaction into an LDS queue), so pixels that are still bouncing use
-                                the lanes of those that have finished; 0 (default): every pixel traces its own shadow
-                                rays one after the other.  Measured: scenes whose long waves are sparse gain 10 %
-                                (TestScene1), others lose 5 % (lock-step + 2 more VGPRs) */
+                                the lanes of those that have finished; 0: every pixel traces its own shadow rays one
+                                after the other; 2 (default): whichever measures faster for the (scene, frame size,
+                                bounces), timed over the first renders like the staged pipeline above.  Scenes whose
+                                long waves are sparse gain 10 % (TestScene1), others lose 5 % (lock-step, more
+                                registers).  Results do not depend on it */
 };
 enum {
     RT_TRAVERSAL_AUTO = 0,
@@ -228,7 +231,7 @@ typedef struct rt_scene_info {
     int64_t flags;          /* RT_SCENE_*                                              */
     int64_t traversal;      /* RT_TRAVERSAL_* a default render (max_bounces 10) uses; for a mid-sized scene under
                                AUTO the measured verdict once there is one (RT_OPTION_WAVEFRONT_MIN_NODES)       */
-    int64_t tight_nodes;    /* 64-byte nodes of the per-primitive tree (0 = not built) */
+    int64_t tight_nodes;    /* 32-byte nodes of the per-primitive tree (0 = not built) */
     int64_t tight_levels;   /* its depth                                               */
     int64_t unbounded_triangles; /* triangle slots with (nearly) collinear or coincident vertices as seen
                                along their stored normal: the reference accepts those on a whole line or

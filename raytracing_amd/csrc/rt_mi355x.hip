@@ -46,24 +46,37 @@ struct rt_ctx {
     // scene buffers
     DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights;
     DevBuf tri_slot_leaf, sphere_slot_leaf;  // tight tree only (rt_bvh.h)
-    // AUTO between the megakernel and the staged pipeline for mid-sized scenes is decided by measurement
-    // (tune_begin): scene size does not tell a triangle soup, where the staged pipeline is 1.8x faster at
-    // 5.7 k nodes, from a field of meshes, where it is 3x slower at 18 k
+    // Which fast kernel renders a frame is decided by measurement where the scene does not tell (tune_begin): the
+    // staged pipeline for mid-sized scenes (a triangle soup is 1.8x faster with it at 5.7 k nodes, a field of meshes
+    // 3x slower at 18 k), the cooperative shadow rays of the megakernel for any scene with bounces (TestScene1 720p
+    // d10 0.50 -> 0.44 ms, teapot 4K 0.58 -> 0.62 ms)
     struct Tune {
+        static constexpr int N = 3;    // [0] megakernel, [1] staged pipeline, [2] megakernel with cooperative shadow rays
         long long scene_serial = -1;   // (upload, frame size, bounces) the measurements belong to
         int w = 0, rows = 0, bounces = -1;
-        float ms[2] = {-1.0f, -1.0f};  // measured GPU time of [0] megakernel, [1] staged pipeline
-        int runs[2] = {0, 0};          // renders started with each: the first is a warm-up (first-use allocation of
-                                       // the path state, code load), the second is the one that is timed
-        hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-        bool pending[2] = {false, false};
-        bool decided() const { return ms[0] >= 0 && ms[1] >= 0; }
+        bool cand[N] = {false, false, false};  // the kernels in the running for this key
+        float ms[N] = {-1.0f, -1.0f, -1.0f};   // measured GPU time: the faster of two timed renders
+        int runs[N] = {0, 0, 0};       // renders started with each: the first is a warm-up (first-use allocation of the
+                                       // path state, code load), the next two run between events
+        int samples[N] = {0, 0, 0};
+        hipEvent_t ev[N][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+        bool pending[N] = {false, false, false};
+        bool decided() const {
+            for (int k = 0; k < N; k++)
+                if (cand[k] && samples[k] < 2) return false;
+            return true;
+        }
+        int best() const {
+            int b = 0;
+            for (int k = 1; k < N; k++)
+                if (cand[k] && ms[k] < ms[b]) b = k;
+            return b;
+        }
     } tune;
     long long scene_serial = 0;
     bool prioritise = true;   // RT_PRIORITISE=0 (development): deal the tiles out in plain row-major order
-    bool coop_shadows = false;  // RT_OPTION_COOP_SHADOWS: the BVH megakernel regroups the shadow rays of sparse bounces over
-                                // the wave.  Off: TestScene1 720p d10 0.49 -> 0.44 ms, but teapot 4K 0.62 -> 0.66 ms and
-                                // TeapotTable 0.67 -> 0.71 ms
+    int coop_shadows = 2;  // RT_OPTION_COOP_SHADOWS: the BVH megakernel regroups the shadow rays of sparse bounces over the
+                           // wave: 0 never, 1 always, 2 (default) where it measures faster (tune_begin)
     bool build_tight = true;  // RT_OPTION_TIGHT_TREE (takes effect at the next upload and at once for renders)
     int tight_min_nodes = 1000;  // RT_OPTION_TIGHT_MIN_NODES: scenes with fewer flat nodes get no tight tree (only the
                                  // staged pipeline walks it: measured slower in the megakernel)
@@ -320,7 +333,7 @@ int rt_create(int device_id, rt_ctx** out) {
     }
     if (const char* v = getenv("RT_PRIORITISE")) ctx->prioritise = atoi(v) != 0;
     if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development overrides
-    if (const char* v = getenv("RT_COOP")) ctx->coop_shadows = atoi(v) != 0;
+    if (const char* v = getenv("RT_COOP")) ctx->coop_shadows = std::min(std::max(atoi(v), 0), 2);
     if (const char* v = getenv("RT_WF_MIN_NODES")) ctx->wf_min_nodes = std::max(0, atoi(v));
     if (const char* v = getenv("RT_TRAVERSAL")) {  // development override of RT_OPTION_TRAVERSAL
         const int t = atoi(v);
@@ -390,7 +403,8 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
             ctx->build_tight = value != 0;
             return RT_OK;
         case RT_OPTION_COOP_SHADOWS:
-            ctx->coop_shadows = value != 0;
+            if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "cooperative shadow rays: 0 never, 1 always, 2 measured");
+            ctx->coop_shadows = value;
             return RT_OK;
         case RT_OPTION_TIGHT_MIN_NODES:
             if (value < 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "node threshold must be >= 0");
@@ -648,8 +662,8 @@ int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out) {
     // a mid-sized scene under AUTO: the measured verdict once there is one (tune_begin)
     const rt_ctx::Tune& t = ctx->tune;
     if (ctx->traversal == RT_TRAVERSAL_AUTO && out->traversal == RT_TRAVERSAL_BVH && t.scene_serial == ctx->scene_serial &&
-        t.decided() && ctx->scene.n_nodes >= ctx->wf_min_nodes)
-        out->traversal = t.ms[1] < t.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
+        t.cand[1] && t.decided())
+        out->traversal = t.best() == 1 ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
     return RT_OK;
 }
 
@@ -693,43 +707,72 @@ static PriorityRect priority_rect(const DevScene& sc, const float* cam, int widt
     return pr;
 }
 
-// AUTO for mid-sized scenes: the first two renders of a (scene, frame size, bounces) run the megakernel, the
-// next two the staged pipeline -- of each pair the first is a warm-up (it may include first-use allocation of
-// the path state and code load), the second runs between two events -- and from then on the faster of the
-// two is used (results are identical either way).  Nothing waits: a measurement is read when its events have
-// completed, until then renders keep the megakernel.  Returns the traversal to force (RT_TRAVERSAL_BVH /
-// WAVEFRONT) or 0 for "no opinion"; *timed = slot whose stop event tune_end must record, or -1.
+// Kernel choice by measurement.  For a (scene, frame size, bounces) the kernels in the running are
+//   [0] the per-lane megakernel                       always
+//   [1] the staged pipeline                           AUTO, mid-sized scenes (RT_OPTION_WAVEFRONT_MIN_NODES .. 100 k nodes)
+//   [2] the megakernel with cooperative shadow rays   RT_OPTION_COOP_SHADOWS = 2, bounces >= 1, 1..32 lights
+// Each in turn renders three frames -- a warm-up (first-use allocation of the path state, code load), then two
+// between events -- and from then on the fastest is used (results are identical either way).  Nothing waits: a
+// measurement is read when its events have completed, until then renders use the plain megakernel.  Returns the
+// kernel to force (RT_TRAVERSAL_BVH / WAVEFRONT, | FORCE_COOP) or 0 for "no opinion"; *timed = slot whose stop event
+// tune_end must record, or -1.
+constexpr int FORCE_COOP = 0x100;
+static int tune_code(int k) { return k == 1 ? RT_TRAVERSAL_WAVEFRONT : (k == 2 ? (RT_TRAVERSAL_BVH | FORCE_COOP) : RT_TRAVERSAL_BVH); }
+static bool tune_candidates(const rt_ctx* ctx, int max_bounces, bool cand[rt_ctx::Tune::N]) {
+    const DevScene& sc = ctx->scene;
+    cand[0] = true, cand[1] = cand[2] = false;
+    if (!ctx->has_scene || sc.bvh == nullptr || sc.bvh_levels > rtb::MAX_LEVELS) return false;
+    if (ctx->traversal != RT_TRAVERSAL_AUTO && ctx->traversal != RT_TRAVERSAL_BVH) return false;
+    const bool large = ctx->traversal == RT_TRAVERSAL_AUTO && max_bounces <= ctx->wf_max_bounces &&
+                       sc.n_nodes >= std::max(ctx->wf_sure_nodes, ctx->wf_min_nodes);
+    if (large) return false;  // the staged pipeline, without asking
+    cand[1] = ctx->traversal == RT_TRAVERSAL_AUTO && max_bounces <= ctx->wf_max_bounces && sc.n_nodes >= ctx->wf_min_nodes;
+    cand[2] = ctx->coop_shadows == 2 && max_bounces >= 1 && sc.lights_len > 0 && sc.lights_len / 6 <= COOP_MAX_LIGHTS;
+    return cand[1] || cand[2];
+}
+// the verdict for this scene and bounce count if there is one (batches and the entry point that must not create
+// events reuse it), else 0
+static int tune_verdict(const rt_ctx* ctx, int max_bounces) {
+    const rt_ctx::Tune& t = ctx->tune;
+    bool cand[rt_ctx::Tune::N];
+    if (!tune_candidates(ctx, max_bounces, cand)) return 0;
+    if (t.scene_serial != ctx->scene_serial || t.bounces != max_bounces || !t.decided()) return 0;
+    for (int k = 0; k < rt_ctx::Tune::N; k++)
+        if (cand[k] != t.cand[k]) return 0;
+    return tune_code(t.best());
+}
 static int tune_begin(rt_ctx* ctx, int w, int local_rows, int max_bounces, hipStream_t st, int* timed) {
     *timed = -1;
-    const DevScene& sc = ctx->scene;
-    if (!ctx->has_scene || ctx->traversal != RT_TRAVERSAL_AUTO || sc.bvh == nullptr || sc.bvh_levels > rtb::MAX_LEVELS ||
-        max_bounces > ctx->wf_max_bounces || sc.n_nodes < ctx->wf_min_nodes || sc.n_nodes >= ctx->wf_sure_nodes)
-        return 0;
+    constexpr int N = rt_ctx::Tune::N;
+    bool cand[N];
+    if (!tune_candidates(ctx, max_bounces, cand)) return 0;
     rt_ctx::Tune& t = ctx->tune;
-    if (t.scene_serial != ctx->scene_serial || t.w != w || t.rows != local_rows || t.bounces != max_bounces) {
+    bool same = t.scene_serial == ctx->scene_serial && t.w == w && t.rows == local_rows && t.bounces == max_bounces;
+    for (int k = 0; k < N; k++) same = same && cand[k] == t.cand[k];
+    if (!same) {
         t.scene_serial = ctx->scene_serial, t.w = w, t.rows = local_rows, t.bounces = max_bounces;
-        t.ms[0] = t.ms[1] = -1.0f;
-        t.runs[0] = t.runs[1] = 0;
-        t.pending[0] = t.pending[1] = false;
+        for (int k = 0; k < N; k++) t.cand[k] = cand[k], t.ms[k] = -1.0f, t.runs[k] = 0, t.samples[k] = 0, t.pending[k] = false;
     }
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < N; k++)
         if (t.pending[k] && hipEventQuery(t.ev[k][1]) == hipSuccess) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, t.ev[k][0], t.ev[k][1]) == hipSuccess) t.ms[k] = ms;
+            if (hipEventElapsedTime(&ms, t.ev[k][0], t.ev[k][1]) == hipSuccess) {
+                t.ms[k] = t.samples[k] == 0 ? ms : std::min(t.ms[k], ms);
+                t.samples[k]++;
+            }
             t.pending[k] = false;
         }
     (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error
-    for (int k = 0; k < 2; k++)
-        if (t.ms[k] < 0 && !t.pending[k]) {
-            const int trav = k == 0 ? RT_TRAVERSAL_BVH : RT_TRAVERSAL_WAVEFRONT;
-            if (t.runs[k]++ == 0) return trav;  // warm-up, not timed
+    for (int k = 0; k < N; k++)
+        if (t.cand[k] && t.samples[k] < 2 && !t.pending[k]) {
+            if (t.runs[k]++ == 0) return tune_code(k);  // warm-up, not timed
             for (int e = 0; e < 2; e++)
                 if (!t.ev[k][e] && hipEventCreate(&t.ev[k][e]) != hipSuccess) return 0;
             if (hipEventRecord(t.ev[k][0], st) != hipSuccess) return 0;
             *timed = k;
-            return trav;
+            return tune_code(k);
         }
-    if (t.decided()) return t.ms[1] < t.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
+    if (t.decided()) return tune_code(t.best());
     return RT_TRAVERSAL_BVH;
 }
 static void tune_end(rt_ctx* ctx, int timed, hipStream_t st) {
@@ -789,7 +832,8 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
     a.ticket_base = 0;
     if (a.tiles_y == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
-    int trav = force_trav ? force_trav : pick_traversal(ctx, a.scene, max_bounces);
+    const bool force_coop = (force_trav & FORCE_COOP) != 0;
+    int trav = (force_trav & 0xFF) ? (force_trav & 0xFF) : pick_traversal(ctx, a.scene, max_bounces);
     // the staged pipeline indexes (pixel, light) work items with 32 bits: beyond that, the megakernel
     if (trav == RT_TRAVERSAL_WAVEFRONT &&
         (size_t)((w + 7) / 8) * ((a.local_rows + 7) / 8) * 64 * (size_t)std::max(a.scene.lights_len / 6, 1) >= 0xFFFFFFF0ull)
@@ -828,7 +872,7 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
     } else if (use_bvh) {
         const bool unb = ctx->info.unbounded_triangles > 0;
         const size_t stacks = (size_t)BLOCK_WAVES * 64 * a.scene.leaf_levels * 4;
-        const bool coop = ctx->coop_shadows && a.scene.lights_len / 6 <= COOP_MAX_LIGHTS && a.scene.lights_len > 0;
+        const bool coop = (force_coop || ctx->coop_shadows == 1) && a.scene.lights_len / 6 <= COOP_MAX_LIGHTS && a.scene.lights_len > 0;
         void (*kern)(const RenderArgs) = coop ? (unb ? k_render_bvh<true, true> : k_render_bvh<false, true>)
                                               : (unb ? k_render_bvh<true, false> : k_render_bvh<false, false>);
         hipLaunchKernelGGL(kern, dim3(n_blocks * n_frames), dim3(64 * BLOCK_WAVES),
@@ -858,11 +902,7 @@ int rt_render_device_noalloc(rt_ctx* ctx, const float camera[14], int max_bounce
                              int32_t* d_bounces, void* stream) {
     // The traversal is the one rt_render_device would take, without its timing of mid-sized scenes (a verdict
     // measured earlier is honoured): nothing here creates events, buffers or anything else.
-    int force = 0;
-    if (ctx && ctx->has_scene && ctx->traversal == RT_TRAVERSAL_AUTO && ctx->tune.scene_serial == ctx->scene_serial &&
-        ctx->tune.ms[0] >= 0 && ctx->tune.ms[1] >= 0 && ctx->scene.n_nodes >= ctx->wf_min_nodes &&
-        ctx->scene.n_nodes < ctx->wf_sure_nodes && max_bounces <= ctx->wf_max_bounces)
-        force = ctx->tune.ms[1] < ctx->tune.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;
+    const int force = ctx ? tune_verdict(ctx, max_bounces) : 0;
     return render_frames(ctx, camera, 1, 0, max_bounces, RT_RENDER_DEFAULT, band_rows, rank, world, d_rgb, d_rgba8,
                          d_primary_id, d_final_id, d_bounces, nullptr, stream, force, true);
 }
@@ -883,10 +923,8 @@ int rt_render_frames_device(rt_ctx* ctx, const float* cameras, int n_frames, int
     int timed = -1, force = 0;
     if (ctx->has_scene && !(flags & RT_RENDER_REFERENCE_ORDER) && n_frames == 1 && hipSetDevice(ctx->device) == hipSuccess)
         force = tune_begin(ctx, w, rt_local_rows(h, band_rows, rank, world), max_bounces, (hipStream_t)stream, &timed);
-    else if (ctx->has_scene && ctx->tune.ms[0] >= 0 && ctx->tune.ms[1] >= 0 && !(flags & RT_RENDER_REFERENCE_ORDER) &&
-             ctx->traversal == RT_TRAVERSAL_AUTO && ctx->scene.n_nodes >= ctx->wf_min_nodes && ctx->scene.n_nodes < ctx->wf_sure_nodes &&
-             ctx->tune.scene_serial == ctx->scene_serial && max_bounces <= ctx->wf_max_bounces)
-        force = ctx->tune.ms[1] < ctx->tune.ms[0] ? RT_TRAVERSAL_WAVEFRONT : RT_TRAVERSAL_BVH;  // batches reuse a verdict
+    else if (ctx->has_scene && !(flags & RT_RENDER_REFERENCE_ORDER))
+        force = tune_verdict(ctx, max_bounces);  // batches reuse a verdict
     for (int f0 = 0; f0 < n_frames; f0 += MAX_BATCH) {  // MAX_BATCH frames per launch
         const int n = std::min(MAX_BATCH, n_frames - f0);
         const size_t off = (size_t)f0 * (size_t)frame_stride;

@@ -28,7 +28,7 @@ def _set_mode(rt, mode):
     rt.set_option(rt.OPTION_TIGHT_TREE, 0 if mode == 3 else 1)
     rt.set_option(rt.OPTION_TIGHT_MIN_NODES, 0 if mode == 4 else 1000)
     rt.set_option(rt.OPTION_WAVEFRONT_MIN_NODES, 1000)
-    rt.set_option(rt.OPTION_COOP_SHADOWS, 1 if mode == 5 else 0)
+    rt.set_option(rt.OPTION_COOP_SHADOWS, {5: 1, 0: 2}.get(mode, 0))     # 2 = the default: where it measures faster
     rt.set_option(rt.OPTION_TRAVERSAL, {0: 0, 1: 1, 2: 2, 3: 3, 4: 3, 5: 2}[mode])
 
 
@@ -418,8 +418,8 @@ def test_untraced_shadow_rays_leave_every_float_as_it_was(mode, label, rt_mode, 
 
 
 def test_auto_times_both_kernels_on_mid_sized_scenes(rt_mode, scene_of):
-    """Between 1000 and 100000 flattened nodes AUTO renders two frames with the megakernel, two with the staged
-    pipeline (of each pair the first is a warm-up, the second runs between events) and then keeps the faster: a
+    """Between 1000 and 100000 flattened nodes AUTO renders three frames each with the megakernel, the staged pipeline
+    and the megakernel with cooperative shadow rays (a warm-up, then two between events) and then keeps the fastest: a
     field of teapots stays on the megakernel (most rays miss everything; the staged pipeline's per-ray bookkeeping
     would dominate); a triangle soup goes to whichever measured faster (the staged pipeline until the megakernel
     learnt to walk the tight tree, since then a close call at this size).  Every frame on the way is the same frame."""
@@ -445,7 +445,7 @@ def test_auto_times_both_kernels_on_mid_sized_scenes(rt_mode, scene_of):
         assert 1000 <= rt.scene_info()["n_nodes"] < 100000 and rt.scene_info()["tight_nodes"] > 0
         cam = sc.camera_for(640, 360)
         frames = []
-        for _ in range(6):
+        for _ in range(11):
             out = torch.empty((360, 640, 4), dtype=torch.uint8, device="cuda")
             rt.render_device(cam, 4, rgba8=out.data_ptr(), stream=st)
             torch.cuda.synchronize()
