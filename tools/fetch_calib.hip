@@ -5,6 +5,7 @@
 //   k_stream  16 B per lane, consecutive lanes consecutive addresses (the pattern the factor 2 was measured on)
 //   k_gather  every lane reads one whole 64-byte record (4 x 16 B, as a BVH node fetch) at a pseudo-random
 //             index: a bijective multiplicative permutation of the record index, so no record is read twice
+//   k_gather32  the same with 32-byte records (2 x 16 B: a node of the tight tree since round 2's 16-bit grid)
 // Known bytes per launch = table size.  Run under `rocprofv3 --pmc FETCH_SIZE`; FETCH_SIZE_KB * 1024 / bytes
 // is the fraction the counter reports for each pattern.
 #include <hip/hip_runtime.h>
@@ -25,6 +26,16 @@ __global__ void k_gather(const float4* __restrict__ t, unsigned n_rec, unsigned 
         const unsigned r = (unsigned)(((unsigned long long)i * mult) & (n_rec - 1));  // n_rec = 2^k, mult odd: a bijection
         const float4 a = t[4 * (size_t)r], b = t[4 * (size_t)r + 1], c = t[4 * (size_t)r + 2], d = t[4 * (size_t)r + 3];
         acc += a.x + b.y + c.z + d.w;
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
+
+__global__ void k_gather32(const float4* __restrict__ t, unsigned n_rec, unsigned mult, float* sink) {
+    float acc = 0;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += gridDim.x * blockDim.x) {
+        const unsigned r = (unsigned)(((unsigned long long)i * mult) & (n_rec - 1));
+        const float4 a = t[2 * (size_t)r], b = t[2 * (size_t)r + 1];
+        acc += a.x + b.y;
     }
     if (acc == 12345.678f) *sink = acc;
 }
@@ -54,6 +65,12 @@ int main(int argc, char** argv) {
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         printf("k_gather  %zu MiB in %.3f ms = %.0f GB/s\n", mib, ms, bytes / ms / 1e6);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_gather32, dim3(256 * 16), dim3(256), 0, 0, t, (unsigned)(bytes / 32), 2654435761u, sink);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("k_gather32 %zu MiB in %.3f ms = %.0f GB/s\n", mib, ms, bytes / ms / 1e6);
     }
     printf("bytes_per_launch %zu\n", bytes);
     return 0;

@@ -1,6 +1,8 @@
 """Render exactly N frames of one bench workload with the fast path and nothing else (no reference-order
 kernel, no CPU work): the program rocprofv3 wraps for the per-workload kernel stats and PMC passes
-(tools/gpu_pmc.sh).  Prints the frame count and the live ms/frame."""
+(tools/gpu_pmc.sh).  Prints the frame count and the live ms/frame.  The library times its candidate kernels over
+the first renders of a scene; for a profile of ONE kernel pin the choice: RT_TRAVERSAL=2|3 (RT_OPTION_TRAVERSAL) and
+RT_COOP=0|1 (read by the library itself) in the environment."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +12,8 @@ from raytracing_amd import RayTracer, host
 name, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10
 sn, pr, w, h, d = B.WORKLOADS[name]
 rt = RayTracer(0)
+if os.environ.get("RT_TRAVERSAL"):
+    rt.set_option(rt.OPTION_TRAVERSAL, int(os.environ["RT_TRAVERSAL"]))
 sc = host.make_scene(sn, params=pr)
 rt.SendPrimitivesToShader(sc)
 cam = sc.camera_for(w, h)
