@@ -119,7 +119,10 @@ enum {
                                 after the other; 2 (default): whichever measures faster for the (scene, frame size,
                                 bounces), timed over the first renders like the staged pipeline above.  Scenes whose
                                 long waves are sparse gain 10 % (TestScene1), others lose 5 % (lock-step, more
-                                registers).  Results do not depend on it */
+                                registers).  Results do not depend on it */,
+    RT_OPTION_GPU_FLATTEN_MIN = 8 /* accel arrays of at least this many floats (default 65536) are validated and
+                                flattened on the GPU, level by level (bit-identical to the host's walk, which smaller
+                                arrays take and which still words every refusal); -1: never */
 };
 enum {
     RT_TRAVERSAL_AUTO = 0,
@@ -257,6 +260,14 @@ int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_t
  * once, depth bound, tight boxes contain their primitive's accepted region + pad).  No context, no GPU. */
 int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, int n_triangles, const float* accel,
                    int64_t accel_len, int tight_min_nodes, rt_scene_info* info, char* err, size_t err_cap);
+
+/* Self-check of the GPU flatten (RT_OPTION_GPU_FLATTEN_MIN): flattens the array on the host and on ctx's GPU,
+ * whatever its size, and compares node records, slot maps, parent links, depth and the nested flag bit for bit.
+ * Returns 1 (identical; the device took the array), 0 (an array too short to hold a node: host only), the host's
+ * refusal (RT_ERR_MALFORMED_ACCEL / RT_ERR_TOO_LARGE) when the device declined it too -- an upload then reports
+ * the host's message -- or RT_ERR_DEVICE with the first difference in err / rt_last_error.  Used by the tests. */
+int rt_check_gpu_flatten(rt_ctx* ctx, const float* accel, int64_t accel_len, int n_spheres, int n_triangles, char* err,
+                         size_t err_cap);
 
 /* Per-function device evaluators of the four intersection routines, one case per element
  * (raytracer_fs.glsl:134-161, 93-113, 114-120, 121-131).  Host arrays; used by the parity

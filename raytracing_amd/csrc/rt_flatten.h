@@ -51,6 +51,9 @@ inline bool meta_nocull(uint32_t meta) {
 }
 constexpr int MAX_LEAF_SLOTS = 31;
 constexpr int64_t SLOT_LIMIT = 1 << 24;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
 inline uint32_t make_meta(bool cont, int kind, int count, int64_t first) {
     return (cont ? META_CONT : 0u) | ((uint32_t)kind << 29) | ((uint32_t)count << 24) | (uint32_t)first;
 }

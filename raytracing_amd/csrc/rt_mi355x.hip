@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "rt_bvh.h"
+#include "rt_gpu_flatten.h"
 #include "rt_kernels.h"
 #include "rt_scene_prep.h"
 #include "rt_wavefront.h"
@@ -46,6 +47,7 @@ struct rt_ctx {
     // scene buffers
     DevBuf geom, plane_geom, tri_slot_id, sphere_slot_id, spheres_aos, planes_aos, tris_aos, lights;
     DevBuf tri_slot_leaf, sphere_slot_leaf;  // tight tree only (rt_bvh.h)
+    DevBuf accel_tmp;                        // the accel array while rt_gpu_flatten.h works on it (grow only)
     // Which fast kernel renders a frame is decided by measurement where the scene does not tell (tune_begin): the
     // staged pipeline for mid-sized scenes (a triangle soup is 1.8x faster with it at 5.7 k nodes, a field of meshes
     // 3x slower at 18 k), the cooperative shadow rays of the megakernel for any scene with bounces (TestScene1 720p
@@ -78,6 +80,9 @@ struct rt_ctx {
     int coop_shadows = 2;  // RT_OPTION_COOP_SHADOWS: the BVH megakernel regroups the shadow rays of sparse bounces over the
                            // wave: 0 never, 1 always, 2 (default) where it measures faster (tune_begin)
     bool build_tight = true;  // RT_OPTION_TIGHT_TREE (takes effect at the next upload and at once for renders)
+    int gpu_flatten_min = 65536;  // RT_OPTION_GPU_FLATTEN_MIN: accel arrays of at least this many floats are flattened on
+                                  // the GPU (rt_gpu_flatten.h), smaller ones on the host (a launch per tree level costs
+                                  // more than the whole host walk there); -1 = never
     int tight_min_nodes = 1000;  // RT_OPTION_TIGHT_MIN_NODES: scenes with fewer flat nodes get no tight tree (only the
                                  // staged pipeline walks it: measured slower in the megakernel)
     int traversal = RT_TRAVERSAL_AUTO;  // RT_OPTION_TRAVERSAL
@@ -333,6 +338,7 @@ int rt_create(int device_id, rt_ctx** out) {
     }
     if (const char* v = getenv("RT_PRIORITISE")) ctx->prioritise = atoi(v) != 0;
     if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development overrides
+    if (const char* v = getenv("RT_GPU_FLATTEN_MIN")) ctx->gpu_flatten_min = atoi(v);
     if (const char* v = getenv("RT_COOP")) ctx->coop_shadows = std::min(std::max(atoi(v), 0), 2);
     if (const char* v = getenv("RT_WF_MIN_NODES")) ctx->wf_min_nodes = std::max(0, atoi(v));
     if (const char* v = getenv("RT_TRAVERSAL")) {  // development override of RT_OPTION_TRAVERSAL
@@ -378,7 +384,7 @@ void rt_destroy(rt_ctx* ctx) {
     DevBuf* all[] = {&ctx->geom,       &ctx->plane_geom, &ctx->tri_slot_id, &ctx->sphere_slot_id, &ctx->spheres_aos,
                      &ctx->planes_aos, &ctx->tris_aos,   &ctx->lights,      &ctx->ticket,         &ctx->fb_rgb,
                      &ctx->fb_rgba8,   &ctx->fb_pid,     &ctx->fb_fid,      &ctx->fb_stats,
-                     &ctx->tri_slot_leaf, &ctx->sphere_slot_leaf};
+                     &ctx->tri_slot_leaf, &ctx->sphere_slot_leaf, &ctx->accel_tmp};
     for (DevBuf* b : all) release(*b);
     for (DevBuf& b : ctx->ev) release(b);
     delete ctx;
@@ -405,6 +411,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
         case RT_OPTION_COOP_SHADOWS:
             if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "cooperative shadow rays: 0 never, 1 always, 2 measured");
             ctx->coop_shadows = value;
+            return RT_OK;
+        case RT_OPTION_GPU_FLATTEN_MIN:
+            if (value < -1) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "GPU flatten threshold must be >= -1");
+            ctx->gpu_flatten_min = value;
             return RT_OK;
         case RT_OPTION_TIGHT_MIN_NODES:
             if (value < 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "node threshold must be >= 0");
@@ -568,13 +578,24 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
     ctx->has_scene = false;
 
-    // everything decided on the host (rt_scene_prep.h): validation, cull preconditions, both trees
+    // Validation + flattening of a large array runs on the GPU (rt_gpu_flatten.h: level by level instead of node by
+    // node; bit-identical to the host's, tests/test_gpu_flatten.py).  If it declines -- an array it would have to
+    // refuse, or a HIP error -- the host does it, and reports what is wrong with the array in its own words.
     rtp::Prepared prep;
+    bool flat_given = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (ctx->gpu_flatten_min >= 0 && accel_len >= ctx->gpu_flatten_min && accel_len >= 8 &&
+        hipSetDevice(ctx->device) == hipSuccess && upload(ctx, ctx->accel_tmp, accel, (size_t)accel_len * 4) == RT_OK)
+        flat_given = rtgf::flatten_on_device((const float*)ctx->accel_tmp.p, accel_len, n_spheres, n_triangles, &prep.flat) == 1;
+    if (std::getenv("RT_PREP_TIMING"))
+        std::fprintf(stderr, "[rt prepare] %-28s %8.1f ms\n", flat_given ? "validate + flatten (GPU)" : "(GPU flatten not used)",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    // everything else the upload decides is decided on the host (rt_scene_prep.h): cull preconditions, both trees
     std::string err;
     rtp::Options opt;
     opt.build_tight = ctx->build_tight, opt.tight_min_nodes = ctx->tight_min_nodes;
     int rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
-                          accel_len, opt, &prep, &err);
+                          accel_len, opt, &prep, &err, flat_given);
     if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
     if (ctx->multi) return multi_upload(ctx, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
     return upload_prepared(ctx, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
@@ -652,6 +673,56 @@ int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, in
         info->unbounded_triangles = prep.unbounded;
     }
     return rc;
+}
+
+int rt_check_gpu_flatten(rt_ctx* ctx, const float* accel, int64_t accel_len, int n_spheres, int n_triangles, char* err,
+                         size_t err_cap) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (accel_len < 0 || n_spheres < 0 || n_triangles < 0 || (accel_len && !accel))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "negative size or null array");
+    rtf::Flat host, dev;
+    std::string msg, host_msg;
+    const int host_rc = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &host, &host_msg);
+    int took = 0;
+    if (accel_len >= 8) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const int rc = upload(ctx, ctx->accel_tmp, accel, (size_t)accel_len * 4);
+        if (rc != RT_OK) return rc;
+        took = rtgf::flatten_on_device((const float*)ctx->accel_tmp.p, accel_len, n_spheres, n_triangles, &dev);
+    }
+    auto differ = [&](const char* what, size_t at) { msg = std::string(what) + " differ at " + std::to_string(at); };
+    if (host_rc != rtf::FLATTEN_OK) {
+        if (took) msg = "the device flattened an array the host refuses: " + host_msg;
+    } else if (accel_len >= 8 && !took) {
+        msg = "the device declined an array the host accepts";
+    } else if (took) {
+        if (dev.nodes.size() != host.nodes.size() || dev.tri_slot_id.size() != host.tri_slot_id.size() ||
+            dev.sphere_slot_id.size() != host.sphere_slot_id.size() || dev.parent.size() != host.parent.size())
+            msg = "array sizes differ";
+        else if (dev.max_depth != host.max_depth || dev.logical_nodes != host.logical_nodes || dev.nested != host.nested)
+            msg = "max_depth / logical_nodes / nested differ";
+        for (size_t i = 0; msg.empty() && i < host.nodes.size(); i++)
+            if (std::memcmp(&host.nodes[i], &dev.nodes[i], sizeof(rtf::FlatNode)) != 0) differ("node records", i);
+        for (size_t i = 0; msg.empty() && i < host.parent.size(); i++)
+            if (host.parent[i] != dev.parent[i]) differ("parent links", i);
+        for (size_t i = 0; msg.empty() && i < host.tri_slot_id.size(); i++)
+            if (host.tri_slot_id[i] != dev.tri_slot_id[i]) differ("triangle slot ids", i);
+        for (size_t i = 0; msg.empty() && i < host.sphere_slot_id.size(); i++)
+            if (host.sphere_slot_id[i] != dev.sphere_slot_id[i]) differ("sphere slot ids", i);
+    }
+    if (err && err_cap) {
+        std::strncpy(err, msg.c_str(), err_cap - 1);
+        err[err_cap - 1] = 0;
+    }
+    if (!msg.empty()) return fail(ctx, RT_ERR_DEVICE, msg);
+    if (host_rc != rtf::FLATTEN_OK) {  // refused by both: what an upload would report
+        if (err && err_cap) {
+            std::strncpy(err, host_msg.c_str(), err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        return fail(ctx, host_rc, host_msg);
+    }
+    return took ? 1 : 0;
 }
 
 int rt_get_scene_info(const rt_ctx* ctx, rt_scene_info* out) {

@@ -128,8 +128,10 @@ inline bool check_containment(const rtf::Flat& flat, const unsigned char* sphere
 }
 
 // Returns rtf::FLATTEN_* (0 = ok).  spheres / triangles: the uploaded SphereStruct / TriangleStruct arrays.
+// flat_given: out->flat already holds the flattened tree (rt_gpu_flatten.h made it on the device).
 inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned char* triangles, int n_triangles,
-                   const float* accel, int64_t accel_len, const Options& opt, Prepared* out, std::string* err) {
+                   const float* accel, int64_t accel_len, const Options& opt, Prepared* out, std::string* err,
+                   bool flat_given = false) {
     // RT_PREP_TIMING=1 (development): wall time of each phase on stderr
     const bool timing = std::getenv("RT_PREP_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -140,7 +142,7 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
         t_last = now;
     };
     rtf::Flat& flat = out->flat;
-    const int rc = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &flat, err);
+    const int rc = flat_given ? (int)rtf::FLATTEN_OK : rtf::flatten(accel, accel_len, n_spheres, n_triangles, &flat, err);
     if (rc != rtf::FLATTEN_OK) return rc;
     lap("validate + flatten");
     for (int k = 0; k < 3; k++) out->extent[k] = 0.0f;

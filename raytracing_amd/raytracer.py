@@ -96,7 +96,7 @@ class RayTracer:
             raise RtError(rc, self._lib.rt_last_error(self._ctx).decode())
 
     OPTION_USE_LDS, OPTION_SUPERTILE, OPTION_TRAVERSAL, OPTION_TIGHT_TREE, OPTION_WAVEFRONT_MIN_NODES = 1, 2, 3, 4, 5
-    OPTION_TIGHT_MIN_NODES, OPTION_COOP_SHADOWS = 6, 7
+    OPTION_TIGHT_MIN_NODES, OPTION_COOP_SHADOWS, OPTION_GPU_FLATTEN_MIN = 6, 7, 8
     TRAVERSAL_AUTO, TRAVERSAL_WAVE, TRAVERSAL_BVH, TRAVERSAL_WAVEFRONT = 0, 1, 2, 3
 
     def set_option(self, option, value):
@@ -218,6 +218,18 @@ class RayTracer:
         n, r = C.c_int(), C.c_int()
         self._check(self._lib.rt_multi_info(self._ctx, C.byref(n), C.byref(r)))
         return {"n_devices": n.value, "uses_rccl": bool(r.value)}
+
+    def check_gpu_flatten(self, accel, n_spheres, n_triangles):
+        """rt_check_gpu_flatten: host and device flatten of the array compared bit for bit.  Returns 1 (identical,
+        flattened on the device) or 0 (too short for the device); raises RtError with the host's refusal when both
+        refuse the array, or with the first difference."""
+        a = np.ascontiguousarray(accel, dtype=np.float32)
+        err = C.create_string_buffer(512)
+        rc = self._lib.rt_check_gpu_flatten(self._ctx, N.ptr(a) if len(a) else None, len(a), int(n_spheres), int(n_triangles),
+                                            err, len(err))
+        if rc < 0:
+            raise RtError(rc, err.value.decode() or self._lib.rt_last_error(self._ctx).decode())
+        return rc
 
     def scene_info(self):
         info = N.rt_scene_info()

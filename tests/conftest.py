@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# torch first: it ships its own copy of the HIP runtime, and a process that has already loaded the system's copy
+# (through librt_mi355x.so) and only then imports torch ends up with a torch that sees no GPU
+import torch  # noqa: F401
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
