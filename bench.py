@@ -522,6 +522,27 @@ def main():
             extras["teapot_1080p_d1_8_frames_per_launch"] = {
                 "ms_per_launch": round(ms8, 4), "ms_per_frame": round(ms8 / 8, 4),
                 "Mrays_per_s": round(rays8 / ms8 / 1e3, 1), "rays": rays8}
+            # configs[4]: the 256-frame camera sweep of the teapot+table scene at depth 8 (host.camera_orbit, the sweep
+            # tests/test_gpu_configs.py checks four frames of against the oracle), 8 frames per launch.  Rays are counted
+            # on every 32nd frame (the reference-order kernel is ~10x slower than the sweep itself).
+            sn, pr, w5, h5, d5 = WORKLOADS["teapottable_1080p_d8"]
+            s5 = host.make_scene(sn, params=pr)
+            rt.SendPrimitivesToShader(s5)
+            sweep = np.stack([host.camera_orbit(f, 256, w5, h5) for f in range(256)])
+            out5 = torch.empty((8, h5, w5, 4), dtype=torch.uint8, device="cuda")
+            for f0 in (0, 8):
+                rt.render_frames_device(sweep[f0:f0 + 8], d5, h5 * w5, rgba8=out5.data_ptr(), stream=s.cuda_stream)
+            e0.record(s)
+            for f0 in range(0, 256, 8):
+                rt.render_frames_device(sweep[f0:f0 + 8], d5, h5 * w5, rgba8=out5.data_ptr(), stream=s.cuda_stream)
+            e1.record(s)
+            torch.cuda.synchronize()
+            ms5 = e0.elapsed_time(e1)
+            rays5 = sum(total_rays(device_stats(rt, torch, sweep[f], d5)) for f in range(0, 256, 32)) * 32
+            extras["teapottable_1080p_d8_sweep_256_frames"] = {
+                "ms_total": round(ms5, 2), "ms_per_frame": round(ms5 / 256, 4), "frames_per_launch": 8,
+                "Mrays_per_s": round(rays5 / ms5 / 1e3, 1), "rays_estimate": rays5,
+                "rays_note": "32 x the rays of frames 0, 32, ..., 224"}
             rt.SendPrimitivesToShader(sc)
             result["extra"] = extras
         if not args.no_cpu:
