@@ -36,21 +36,23 @@ while time.time() < t_end:
                 right = np.array([1.0, 0, 0])
             cam = host.camera_pack(pos, view, right, 1.0, 1.6, 0.9, W, H)
             planes = {}
-            for mode in (None, 1, 2, 3):
+            for mode in (None, 1, 2, 3, 5):
                 pid = torch.empty((H, W), dtype=torch.int32, device="cuda"); fid = torch.empty_like(pid)
                 rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-                if mode is not None:
-                    rt.set_option(rt.OPTION_TRAVERSAL, mode)
+                if mode is not None:   # 5 = the BVH megakernel with cooperative shadow rays
+                    rt.set_option(rt.OPTION_TRAVERSAL, 2 if mode == 5 else mode)
+                    rt.set_option(rt.OPTION_COOP_SHADOWS, 1 if mode == 5 else 0)
                 rt.render_device(cam, depth, rgb=rgb.data_ptr(), primary_id=pid.data_ptr(), final_id=fid.data_ptr(),
                                  reference_order=mode is None, stream=st)
                 torch.cuda.synchronize()
                 planes[mode] = (pid, fid, rgb.view(torch.int32))
             total += 1
-            for mode in (1, 2, 3):
+            for mode in (1, 2, 3, 5):
                 d = [int((planes[mode][k] != planes[None][k]).sum()) for k in range(3)]
                 if any(d):
                     bad += 1
                     print(f"MISMATCH {name} {params} mode {mode} kind {kind} pos {pos.tolist()} view {view.tolist()}: "
                           f"primary {d[0]} final {d[1]} rgb words {d[2]}", flush=True)
     print(f"... {total} cameras, {bad} mismatching (camera, traversal) pairs", flush=True)
-print(f"stress parity: {total} cameras x 3 traversals, {bad} mismatches")
+print(f"stress parity: {total} cameras x 4 traversals (wave, bvh, wavefront + tight tree, bvh + cooperative shadow rays) "
+      f"against the reference-order kernel, every float of rgb and both id planes: {bad} mismatches")
