@@ -117,3 +117,29 @@ def test_uploads_use_it_and_render_the_same_frame(rt, scene_of):
     bad[7] = 2.5
     with pytest.raises(RtError, match="bad count"):
         rt.SendPrimitivesToShader(Scene(sc.spheresData, sc.planesData, sc.trianglesData, bad, sc.lightsData, sc.cameraData))
+
+
+def test_randomly_damaged_arrays_get_the_same_verdict_from_both(rt, scene_of):
+    """300 copies of the teapot's array with a few floats overwritten (counts, offsets, ids, boxes, leaf flags; small
+    integers, huge values, fractions, negatives, NaN, inf): the device either flattens it exactly as the host does
+    or declines exactly when the host refuses -- never a third outcome, and never a fault (every index the kernels
+    read from the array is checked before use)."""
+    sc = scene_of("TeapotScene")
+    good = sc.AccelerationStructureData
+    S, T = len(sc.spheresData), len(sc.trianglesData)
+    g = np.random.default_rng(99)
+    values = [0.0, 1.0, 2.0, 7.0, 8.0, 9.0, 31.0, 32.0, 100.0, 1022.0, 1023.0, 1024.0, 5000.0, float(len(good)), 1.6e7, 1.7e7,
+              3e9, 1e30, -1.0, -8.0, 0.5, 2.5, np.nan, np.inf, -np.inf]
+    accepted = refused = 0
+    for _ in range(300):
+        a = good.copy()
+        for _ in range(int(g.integers(1, 4))):
+            where = int(g.integers(0, len(a))) if g.random() < 0.5 else int(g.integers(0, 64))   # anywhere / near the root
+            a[where] = values[int(g.integers(0, len(values)))] if g.random() < 0.8 else float(g.integers(0, len(a)))
+        try:
+            assert rt.check_gpu_flatten(a, S, T) == 1
+            accepted += 1
+        except RtError as e:
+            assert e.code in (-2, -6), (e.code, str(e))        # malformed / too large: the host's refusal, device declined
+            refused += 1
+    assert accepted > 20 and refused > 20, (accepted, refused)
