@@ -98,7 +98,24 @@ struct Builder {
     Bvh& out;
     std::atomic<int> levels{0};
     static constexpr int BINS = 16;
-    static constexpr size_t FORK_MIN = 1 << 15;  // subtrees at least this large may be built by another thread
+    static constexpr size_t FORK_MIN = 1 << 15;   // subtrees at least this large may be built by another thread
+    static constexpr size_t SWEEP_MIN = 1 << 17;  // nodes at least this large are binned by several threads
+    struct Bins {
+        Box bb[3][BINS];
+        double bw[3][BINS];
+        size_t bn[3][BINS];
+        void reset() {
+            for (int ax = 0; ax < 3; ax++)
+                for (int k = 0; k < BINS; k++) bb[ax][k].reset(), bw[ax][k] = 0, bn[ax][k] = 0;
+        }
+        void add(const Bins& o) {
+            for (int ax = 0; ax < 3; ax++)
+                for (int k = 0; k < BINS; k++) {
+                    if (o.bn[ax][k]) bb[ax][k].grow(o.bb[ax][k].lo, o.bb[ax][k].hi);
+                    bw[ax][k] += o.bw[ax][k], bn[ax][k] += o.bn[ax][k];
+                }
+        }
+    };
 
     // Builds items[b, e) and returns its ref and box.  A subtree over m items has exactly m - 1 inner
     // nodes: it owns out.nodes[base, base + m - 1) (root first, then the left subtree, then the right), so
@@ -111,31 +128,79 @@ struct Builder {
         }
         const int room = MAX_LEVELS - level;  // levels left including this node: n <= 2^room holds
         const size_t n = e - b;
+        if (n == 2) {
+            // half of all nodes: what the binned search below decides for two items, without the bins -- the first
+            // axis along which the centroids differ separates them (every such split costs the same), lower first
+            Item &p = items[b], &q = items[b + 1];
+            for (int k = 0; k < 3; k++) {
+                const float cp = 0.5f * p.lo[k] + 0.5f * p.hi[k], cq = 0.5f * q.lo[k] + 0.5f * q.hi[k];
+                if (cp == cq) continue;
+                if (cq < cp) std::swap(p, q);
+                break;
+            }
+            for (int seen = levels.load(); level + 1 > seen && !levels.compare_exchange_weak(seen, level + 1);) {
+            }
+            Node& nd = out.nodes[base];
+            nd.set_child(0, p.lo, p.hi, p.ref), nd.set_child(1, q.lo, q.hi, q.ref);
+            nd.pad[0] = nd.pad[1] = 0;
+            box->grow(p.lo, p.hi);
+            box->grow(q.lo, q.hi);
+            return base | ((ref_nocull(p.ref) || ref_nocull(q.ref)) ? NOCULL : 0u);
+        }
         const size_t child_cap = (room - 1 >= 31) ? (size_t)1 << 31 : (size_t)1 << (room - 1);
+        // The passes over a large node's items (centroid bounds, then the bins of all three axes in one sweep) are
+        // cut into ranges for the threads this subtree may still fork: box unions are min/max and the bin weights
+        // are small integers summed in double, so the result does not depend on how the range was cut.
+        const int helpers = (forks > 0 && n >= SWEEP_MIN) ? (1 << std::min(forks, 4)) : 1;
+        auto sweep = [&](auto&& body) {  // body(thread index, first, last)
+            if (helpers == 1) return body(0, b, e);
+            std::vector<std::thread> pool;
+            for (int t = 1; t < helpers; t++) pool.emplace_back([&, t] { body(t, b + n * t / helpers, b + n * (t + 1) / helpers); });
+            body(0, b, b + n / helpers);
+            for (std::thread& th : pool) th.join();
+        };
         Box cb;  // centroid bounds
         cb.reset();
-        for (size_t i = b; i < e; i++) {
-            float c[3];
-            for (int k = 0; k < 3; k++) c[k] = 0.5f * items[i].lo[k] + 0.5f * items[i].hi[k];
-            cb.grow(c, c);
+        {
+            std::vector<Box> part(helpers);
+            sweep([&](int t, size_t first, size_t last) {
+                Box c_;
+                c_.reset();
+                for (size_t i = first; i < last; i++) {
+                    float c[3];
+                    for (int k = 0; k < 3; k++) c[k] = 0.5f * items[i].lo[k] + 0.5f * items[i].hi[k];
+                    c_.grow(c, c);
+                }
+                part[t] = c_;
+            });
+            for (const Box& p : part) cb.grow(p.lo, p.hi);
         }
-        int best_axis = -1, best_bin = -1;
-        double best_cost = 1e300;
         double scale[3];
         for (int ax = 0; ax < 3; ax++) {
             const double ext = (double)cb.hi[ax] - cb.lo[ax];
             scale[ax] = ext > 0 ? BINS / ext : 0;
-            if (!(ext > 0)) continue;
-            Box bb[BINS];
-            double bw[BINS];
-            size_t bn[BINS];
-            for (int k = 0; k < BINS; k++) bb[k].reset(), bw[k] = 0, bn[k] = 0;
-            for (size_t i = b; i < e; i++) {
-                const int k = bin_of(items[i], ax, cb.lo[ax], scale[ax]);
-                bb[k].grow(items[i].lo, items[i].hi);
-                bw[k] += items[i].weight;
-                bn[k]++;
-            }
+        }
+        std::vector<Bins> bins(helpers);
+        sweep([&](int t, size_t first, size_t last) {
+            Bins& bs = bins[t];
+            bs.reset();
+            for (size_t i = first; i < last; i++)
+                for (int ax = 0; ax < 3; ax++) {
+                    if (!(scale[ax] > 0)) continue;
+                    const int k = bin_of(items[i], ax, cb.lo[ax], scale[ax]);
+                    bs.bb[ax][k].grow(items[i].lo, items[i].hi);
+                    bs.bw[ax][k] += items[i].weight;
+                    bs.bn[ax][k]++;
+                }
+        });
+        for (int t = 1; t < helpers; t++) bins[0].add(bins[t]);
+        int best_axis = -1, best_bin = -1;
+        double best_cost = 1e300;
+        for (int ax = 0; ax < 3; ax++) {
+            if (!(scale[ax] > 0)) continue;
+            const Box* bb = bins[0].bb[ax];
+            const double* bw = bins[0].bw[ax];
+            const size_t* bn = bins[0].bn[ax];
             double right_cost[BINS];
             Box acc;
             acc.reset();

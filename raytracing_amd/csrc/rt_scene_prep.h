@@ -159,27 +159,37 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
     if (out->contained)
         for (int32_t leaf : unbounded_leaves) rtf::mark_unbounded(&flat, leaf);
     lap("cull preconditions");
-    // re-treed leaves for the per-lane kernels (only for nested trees, rt_bvh.h)
-    out->bvh = rtb::Bvh();
-    if (flat.nested) rtb::build(flat, &out->bvh);
-    lap("re-tree the leaves (SAH)");
+    // re-treed leaves for the per-lane kernels (only for nested trees, rt_bvh.h) and, side by side on a second
+    // thread (both builders fork further below their first levels; neither reads what the other writes), the
     // tight per-primitive tree for the staged pipeline's rays (rt_bvh.h build_tight): large scenes whose
     // primitives were just verified to sit inside their leaves with matching normals
+    out->bvh = rtb::Bvh();
     out->tight = rtb::Bvh();
     out->tri_slot_leaf.clear(), out->sphere_slot_leaf.clear();
     const float max_extent = std::fmax(out->extent[0], std::fmax(out->extent[1], out->extent[2]));
     out->tight_e = 4.0f * max_extent;  // origins up to 3 scene radii from the world origin
     out->pad_tri = out->tight_e * (1.0f / 16384.0f), out->pad_sphere = out->tight_e * (1.0f / 256.0f);
-    if (opt.build_tight && out->contained && !out->bvh.nodes.empty() && (int64_t)flat.nodes.size() >= opt.tight_min_nodes &&
-        max_extent <= 1e6f) {
-        rtb::TightInput in;
-        in.tris = triangles, in.spheres = spheres;
-        in.pad_tri = out->pad_tri, in.pad_sphere = out->pad_sphere;
-        in.tri_unbounded = &out->tri_unbounded;
-        rtb::build_tight(flat, in, &out->tight, &out->tri_slot_leaf, &out->sphere_slot_leaf);
-        if (out->tight.levels > rtb::MAX_LEVELS) out->tight = rtb::Bvh();
+    const bool want_tight = opt.build_tight && out->contained && flat.nested && (int64_t)flat.nodes.size() >= opt.tight_min_nodes &&
+                            max_extent <= 1e6f;
+    std::thread tight_builder;
+    if (want_tight)
+        tight_builder = std::thread([&] {
+            rtb::TightInput in;
+            in.tris = triangles, in.spheres = spheres;
+            in.pad_tri = out->pad_tri, in.pad_sphere = out->pad_sphere;
+            in.tri_unbounded = &out->tri_unbounded;
+            rtb::build_tight(flat, in, &out->tight, &out->tri_slot_leaf, &out->sphere_slot_leaf);
+        });
+    if (flat.nested) rtb::build(flat, &out->bvh);
+    lap("re-tree the leaves (SAH)");
+    if (want_tight) {
+        tight_builder.join();
+        if (out->bvh.nodes.empty() || out->tight.levels > rtb::MAX_LEVELS) {  // (no leaf holds a primitive / too deep)
+            out->tight = rtb::Bvh();
+            out->tri_slot_leaf.clear(), out->sphere_slot_leaf.clear();
+        }
     }
-    lap("tight tree (SAH)");
+    lap("tight tree (SAH), the rest");
     out->tight_q = rtb::QBvh();
     if (!out->tight.nodes.empty() && !rtb::quantize(out->tight, &out->tight_q)) out->tight = rtb::Bvh();
     lap("tight tree -> 16-bit grid");
