@@ -263,7 +263,8 @@ int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, in
 
 /* Self-check of the GPU flatten (RT_OPTION_GPU_FLATTEN_MIN): flattens the array on the host and on ctx's GPU,
  * whatever its size, and compares node records, slot maps, parent links, depth and the nested flag bit for bit.
- * Returns 1 (identical; the device took the array), 0 (an array too short to hold a node: host only), the host's
+ * Returns 1 (identical; the device took the array), 0 (an array too short to hold a node, or a tree of more than
+ * 1024 levels, which the device leaves to the host's linear walk: host only), the host's
  * refusal (RT_ERR_MALFORMED_ACCEL / RT_ERR_TOO_LARGE) when the device declined it too -- an upload then reports
  * the host's message -- or RT_ERR_DEVICE with the first difference in err / rt_last_error.  Used by the tests. */
 int rt_check_gpu_flatten(rt_ctx* ctx, const float* accel, int64_t accel_len, int n_spheres, int n_triangles, char* err,

@@ -205,10 +205,17 @@ __global__ void k_emit(const float* __restrict__ acc, int64_t n_spheres, Work w,
     }
 }
 
+// One launch and one 8-byte read-back per level: a tree deeper than this (a chain of one-child branches can be
+// len / 9 levels deep, and the host walks it in linear time) is left to the host.
+constexpr size_t MAX_DEVICE_LEVELS = 1024;
+
 // Returns 1 and fills *out if the array was flattened on the current device, 0 if it must go through flatten()
-// on the host instead (refused input, a HIP error, an array too large for 32-bit positions).  d_acc: the array on
-// the device (len floats).  Temporary device memory: 48 bytes per possible node + the outputs.
-inline int flatten_on_device(const float* d_acc, int64_t len, int64_t n_spheres, int64_t n_tris, rtf::Flat* out) {
+// on the host instead (refused input, a HIP error, an array too large for 32-bit positions, a tree deeper than
+// MAX_DEVICE_LEVELS -- *too_deep then says so).  d_acc: the array on the device (len floats).  Temporary device
+// memory: 48 bytes per possible node + the outputs.
+inline int flatten_on_device(const float* d_acc, int64_t len, int64_t n_spheres, int64_t n_tris, rtf::Flat* out,
+                             bool* too_deep = nullptr) {
+    if (too_deep) *too_deep = false;
     if (len < 8 || len >= (int64_t)1 << 31) return 0;
     const uint32_t budget = (uint32_t)(len / 8 + 1);
     int32_t* pool = nullptr;
@@ -240,6 +247,10 @@ inline int flatten_on_device(const float* d_acc, int64_t len, int64_t n_spheres,
         ok = hipMemcpy(h_state, state, 8, hipMemcpyDeviceToHost) == hipSuccess && !(h_state[1] & FLAG_REFUSED) && h_state[0] <= budget;
         levels.emplace_back(fb, fe);
         fb = fe, fe = h_state[0];
+        if (ok && fb < fe && levels.size() >= MAX_DEVICE_LEVELS) {
+            if (too_deep) *too_deep = true;
+            ok = false;
+        }
     }
     const uint32_t n_logical = fe;
     for (size_t l = levels.size(); ok && l-- > 0;)

@@ -684,16 +684,17 @@ int rt_check_gpu_flatten(rt_ctx* ctx, const float* accel, int64_t accel_len, int
     std::string msg, host_msg;
     const int host_rc = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &host, &host_msg);
     int took = 0;
+    bool too_deep = false;
     if (accel_len >= 8) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         const int rc = upload(ctx, ctx->accel_tmp, accel, (size_t)accel_len * 4);
         if (rc != RT_OK) return rc;
-        took = rtgf::flatten_on_device((const float*)ctx->accel_tmp.p, accel_len, n_spheres, n_triangles, &dev);
+        took = rtgf::flatten_on_device((const float*)ctx->accel_tmp.p, accel_len, n_spheres, n_triangles, &dev, &too_deep);
     }
     auto differ = [&](const char* what, size_t at) { msg = std::string(what) + " differ at " + std::to_string(at); };
     if (host_rc != rtf::FLATTEN_OK) {
         if (took) msg = "the device flattened an array the host refuses: " + host_msg;
-    } else if (accel_len >= 8 && !took) {
+    } else if (accel_len >= 8 && !took && !too_deep) {
         msg = "the device declined an array the host accepts";
     } else if (took) {
         if (dev.nodes.size() != host.nodes.size() || dev.tri_slot_id.size() != host.tri_slot_id.size() ||

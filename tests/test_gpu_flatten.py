@@ -61,6 +61,9 @@ def test_hand_made_trees(rt):
     for _ in range(60):                                                                      # 60 levels, one node each
         deep = _branch([0, 0, 0, 1, 1, 1], [deep])
     assert rt.check_gpu_flatten(np.array(deep, dtype=np.float32), S, T) == 1
+    for _ in range(1100):                                                                    # 1160 levels: one launch per
+        deep = _branch([0, 0, 0, 1, 1, 1], [deep])                                           # level would not pay, the host
+    assert rt.check_gpu_flatten(np.array(deep, dtype=np.float32), S, T) == 0                 # walks it (and uploads do too)
 
 
 def test_refused_arrays_are_declined_with_the_hosts_message(rt, scene_of):
