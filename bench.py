@@ -411,12 +411,23 @@ def main():
         torch.cuda.synchronize()
 
     step_no = [0]
+    # N > 1: HIP events around each render launch of the timed region (the first 512 steps), on the launch stream --
+    # the roofline's kernel time must not include what the stream waits for between launches (the exchange).  N = 1:
+    # nothing lies between the launches, one pair around the whole region measures them without touching the stream.
+    launch_events = []
 
-    def step():
+    def step(timed=False):
         # step s renders while the exchange of step s-1 is in flight on RCCL's stream
         b, other = bufs[step_no[0] % 2], bufs[(step_no[0] + 1) % 2]
         b.finish()               # this buffer's previous exchange: scanline order on the frame's owner
-        b.render(cams, depth)
+        if timed and len(launch_events) < 512:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record(stream)
+            b.render(cams, depth)
+            pair[1].record(stream)
+            launch_events.append(pair)
+        else:
+            b.render(cams, depth)
         other.wait_gather()      # at most one collective in flight (it has overlapped this step's render)
         b.gather_async()
         step_no[0] += 1
@@ -440,7 +451,7 @@ def main():
     t0 = time.perf_counter()
     e0.record(stream)
     for _ in range(args.steps):
-        step()
+        step(timed=world > 1)
     drain()
     e1.record(stream)
     fence()
@@ -455,7 +466,8 @@ def main():
             if not torch.equal(ref, frame):
                 raise SystemExit(f"rank {rank}: assembled frame {f} differs from the single-GPU render")
         dbg("verified", [f for f, _ in last.owned_frames()])
-    kernel_ms = e0.elapsed_time(e1) / args.steps  # per render launch (one per step), on the launch stream
+    # per render launch (one per step), on the launch stream
+    kernel_ms = (sum(a.elapsed_time(b) for a, b in launch_events) / len(launch_events)) if launch_events else e0.elapsed_time(e1) / args.steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
