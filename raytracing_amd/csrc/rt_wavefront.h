@@ -329,6 +329,8 @@ struct WfClosestJob {
 
 #ifndef RT_WF_WAVES_PER_EU
 #define RT_WF_WAVES_PER_EU 6  // 80 VGPRs (20 B of spill): Soup1M 4K 148.8 -> 140.3 ms; 8 waves (64 VGPRs) spill 88 B: 375 ms
+                              // (round 2's kernels, Soup1M 4K: 6 waves 49.8 ms; 5 waves / 96 VGPRs 52.7; 4 waves / no spills
+                              // 59.1; 7 waves / 72 VGPRs 64.9)
 #endif
 template <bool UNB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_PER_EU, 8))) void k_wf_closest(const WfArgs a) {
