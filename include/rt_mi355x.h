@@ -112,14 +112,16 @@ enum {
                                 without asking */
     RT_OPTION_TIGHT_MIN_NODES = 6, /* scenes with fewer flattened node records get no tight tree (default 1000; only
                                 the staged pipeline walks it -- in the megakernel it measured slower) */
-    RT_OPTION_COOP_SHADOWS = 7 /* 1: the BVH megakernel keeps the lanes of a wave in step through the mirror loop and,
-                                in bounces where fewer than 40 lanes need shadow rays, regroups those rays over all
-                                64 lanes (ballot compaction into an LDS queue), so pixels that are still bouncing use
-                                the lanes of those that have finished; 0: every pixel traces its own shadow rays one
-                                after the other; 2 (default): whichever measures faster for the (scene, frame size,
-                                bounces), timed over the first renders like the staged pipeline above.  Scenes whose
-                                long waves are sparse gain 10 % (TestScene1), others lose 5 % (lock-step, more
-                                registers).  Results do not depend on it */,
+    RT_OPTION_COOP_SHADOWS = 7 /* 1: the BVH megakernel keeps the lanes of a wave in step through the mirror loop and
+                                regroups the shadow rays of every shading step over all 64 lanes (ballot compaction
+                                into an LDS queue of the rays whose light term is not an exact zero), so pixels that
+                                are still bouncing use the lanes of those that have finished and a step takes
+                                ceil(needed rays / 64) rounds instead of one per light; 0: every pixel traces its own
+                                shadow rays one after the other; 2 (default): whichever measures faster for the
+                                (scene, frame size, bounces), timed over the first renders like the staged pipeline
+                                above.  Scenes with bounces gain 5-20 % (TestScene1, TeapotTable), the teapot frame
+                                loses 8-30 % (lock-step, light rays formed again per queue entry).  Results do not
+                                depend on it */,
     RT_OPTION_GPU_FLATTEN_MIN = 8 /* accel arrays of at least this many floats (default 65536) are validated and
                                 flattened on the GPU, level by level (bit-identical to the host's walk, which smaller
                                 arrays take and which still words every refusal); -1: never */
