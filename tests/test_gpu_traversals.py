@@ -507,3 +507,28 @@ def test_lds_resident_kernel_matches_the_oracle(name, depth, tight_everywhere, r
     finally:
         rt.set_option(rt.OPTION_USE_LDS, 0)
         rt.set_option(rt.OPTION_TIGHT_MIN_NODES, 1000)
+
+
+@pytest.mark.parametrize("n_lights", [1, 9, 20, 32, 33])
+def test_cooperative_kernel_with_many_lights(n_lights, rt_mode, scene_of):
+    """The cooperative kernel queues at most 8 lights' rays per fill (9, 20 and 32 lights: several fills per
+    shading step, 64 lanes x 8 lights fill the queue exactly) and keeps one mask bit per light: from 33 lights on
+    the plain megakernel renders the frame.  Lights behind surfaces, one with a negative colour, one black."""
+    rt = rt_mode
+    sc = scene_of("TestScene1")
+    g = np.random.default_rng(n_lights)
+    lights = np.zeros((n_lights, 6), np.float32)
+    lights[:, 0:3] = g.uniform([-12, -2, -12], [12, 14, 12], (n_lights, 3))     # some below the floor
+    lights[:, 3:6] = g.uniform(2, 30, (n_lights, 3))
+    if n_lights > 2:
+        lights[1, 3:] *= -1.0
+        lights[2, 3:] = 0.0
+    many = Scene(sc.spheresData, sc.planesData, sc.trianglesData, sc.AccelerationStructureData, lights.ravel(), sc.cameraData)
+    cam = sc.camera_for(128, 72)
+    ref = oracle_render(many, cam, 6, threads=16)
+    _set_mode(rt, 5)
+    out = _render(rt, many, cam, 6)
+    assert_frame_matches(out, ref, f"{n_lights} lights, cooperative")
+    _set_mode(rt, 2)
+    plain = _render(rt, many, cam, 6)
+    assert np.array_equal(out["rgb"].view(np.uint32), plain["rgb"].view(np.uint32))
