@@ -8,11 +8,14 @@ from raytracing_amd import parallel as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1, 3], ids=["auto", "wave", "wavefront"])
+@pytest.fixture(params=[0, 1, 3, 5], ids=["auto", "wave", "wavefront", "bvh+coop-shadows"])
 def traversal(request, rt):
-    rt.set_option(rt.OPTION_TRAVERSAL, request.param)
+    """5 = the BVH megakernel with cooperative shadow rays forced (by default it is used where it measures faster)."""
+    rt.set_option(rt.OPTION_TRAVERSAL, 2 if request.param == 5 else request.param)
+    rt.set_option(rt.OPTION_COOP_SHADOWS, 1 if request.param == 5 else 2)
     yield request.param
     rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)
+    rt.set_option(rt.OPTION_COOP_SHADOWS, 2)
 
 
 @pytest.mark.parametrize("w,h,band,world", [(160, 90, 16, 2), (123, 77, 8, 3), (320, 180, 16, 8), (64, 20, 32, 2)])
