@@ -996,7 +996,10 @@ int rt_render_frames_device(rt_ctx* ctx, const float* cameras, int n_frames, int
     if (ctx->has_scene && !(flags & RT_RENDER_REFERENCE_ORDER) && n_frames == 1 && hipSetDevice(ctx->device) == hipSuccess)
         force = tune_begin(ctx, w, rt_local_rows(h, band_rows, rank, world), max_bounces, (hipStream_t)stream, &timed);
     else if (ctx->has_scene && !(flags & RT_RENDER_REFERENCE_ORDER))
-        force = tune_verdict(ctx, max_bounces);  // batches reuse a verdict
+        // Batches reuse a verdict -- except the cooperative megakernel's: it wins single frames by shortening their
+        // tail, and the frames of a batch fill each other's tails (measured, 8 frames per launch: TeapotTable 0.370 ms
+        // per frame plain / 0.412 cooperative, TestScene1 0.133 / 0.150, teapot 0.187 / 0.233; tools/sweep_probe.py)
+        force = tune_verdict(ctx, max_bounces) & ~FORCE_COOP;
     for (int f0 = 0; f0 < n_frames; f0 += MAX_BATCH) {  // MAX_BATCH frames per launch
         const int n = std::min(MAX_BATCH, n_frames - f0);
         const size_t off = (size_t)f0 * (size_t)frame_stride;
