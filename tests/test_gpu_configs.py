@@ -7,6 +7,8 @@ through the C ABI, plus a bounded randomised sweep of every traversal against th
   configs[4]  TeapotTable orbit at 1920x1080 depth 8: frames 0/64/128/192 against oracle checksums are in
               tests/test_gpu_parity.py (golden_cases.big_cases); here the same frames band-sharded.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -118,7 +120,9 @@ def test_stress_every_traversal_against_the_oracle(name, params, depth, ext, rt,
     the fixed cases do not have (eye inside the mesh, grazing the mirror floor, axis-aligned rays)."""
     sc = scene_of(name, params)
     w, h = 96, 54
-    cams = _stress_cameras(np.random.default_rng(20250211), ext, 25, w, h)
+    # RT_STRESS_CAMERAS / RT_STRESS_SEED (development): a longer sweep with other cameras, for the record in profiles/
+    n_cams = int(os.environ.get("RT_STRESS_CAMERAS", "25"))
+    cams = _stress_cameras(np.random.default_rng(int(os.environ.get("RT_STRESS_SEED", "20250211"))), ext, n_cams, w, h)
     refs = [oracle_render(sc, cam, depth, threads=16) for cam in cams]
     try:
         for mode, label in MODES:
@@ -133,5 +137,5 @@ def test_stress_every_traversal_against_the_oracle(name, params, depth, ext, rt,
     finally:
         rt.set_option(rt.OPTION_TIGHT_TREE, 1)
         rt.set_option(rt.OPTION_TIGHT_MIN_NODES, 1000)
-        rt.set_option(rt.OPTION_COOP_SHADOWS, 0)
+        rt.set_option(rt.OPTION_COOP_SHADOWS, 2)
         rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)
