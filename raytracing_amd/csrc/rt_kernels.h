@@ -689,6 +689,11 @@ struct RenderArgs {
     int local_rows;      // rows this launch renders
     int band_rows, rank, world;
     int tiles_x, tiles_y, supertile;
+    // Order by the previous frame (k_render_bvh, single frames with >= RT_HEAT_BOUNCES bounces allowed): order[k] =
+    // the super-tile dealt out k-th (k_rank_supers: those where some path bounced that often last time first), or
+    // null; heat_out[super-tile] is set by the waves of this launch whose paths bounce that often.
+    const int32_t* order;
+    uint32_t* heat_out;
     float* rgb;
     uint32_t* rgba8;
     int32_t* primary_id;
@@ -775,14 +780,21 @@ __device__ __forceinline__ void priority_super(int k, int sx_n, PriorityRect pr,
         *sx = k % sx_n, *sy = pr.y1 + 1 + k / sx_n;
     }
 }
-__device__ __forceinline__ bool block_to_tile(int b, int st, int tiles_x, int tiles_y, PriorityRect pr, int* tx, int* ty) {
+__device__ __forceinline__ bool block_to_tile(int b, int st, int tiles_x, int tiles_y, PriorityRect pr, int* tx, int* ty,
+                                              const int32_t* order = nullptr, int* super_out = nullptr) {
     const int x = b & 7, j = b >> 3;
     const int per = st * st;
     const int super = (j / per) * 8 + x;
     const int in = j % per;
     const int sx_n = (tiles_x + st - 1) / st;
     int sx, sy;
-    priority_super(super, sx_n, pr, &sx, &sy);
+    if (order) {
+        const int idx = order[super];  // (a permutation of the padded super-tile range)
+        sx = idx % sx_n, sy = idx / sx_n;
+    } else {
+        priority_super(super, sx_n, pr, &sx, &sy);
+    }
+    if (super_out) *super_out = sy * sx_n + sx;
     *tx = sx * st + in % st;
     *ty = sy * st + in / st;
     return *tx < tiles_x && *ty < tiles_y;
@@ -840,6 +852,56 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
     }
 }
 
+// ---- order by the previous frame ---------------------------------------------------------------------
+// A frame with mirrors ends when its longest wave ends, and the longest waves are those whose paths keep bouncing
+// (TestScene1 720p: 300 us of a 400 us launch, and dealt out bottom to top they start 100 us into it).  Where they
+// are is not known before the frame is rendered -- but it is known from the frame before: waves whose paths bounce
+// RT_HEAT_BOUNCES times or more mark their super-tile, and the next launch of the same size deals the marked
+// super-tiles out first (one workgroup ranks them: heat -> order, a stable partition of the padded super-tile
+// range).  Scheduling only: order is a permutation whatever the marks say, every tile is rendered exactly once, and
+// a camera cut merely costs that frame the head start.
+#ifndef RT_HEAT_BOUNCES
+#define RT_HEAT_BOUNCES 3  // launches whose paths may bounce at least this often take part
+#endif
+#ifndef RT_HEAT_MIN_TICKS
+#define RT_HEAT_MIN_TICKS 3000u  // waves that lived 30 us or longer report
+#endif
+__global__ __launch_bounds__(1024) void k_rank_supers(const uint32_t* __restrict__ heat, int n, int32_t* __restrict__ order) {
+    __shared__ int part[1024];
+    __shared__ int total_hot;
+    __shared__ uint32_t longest;
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = t * per, e = min(n, b + per);
+    if (t == 0) longest = 0u;
+    __syncthreads();
+    uint32_t mx = 0u;
+    for (int i = b; i < e; i++) mx = max(mx, heat[i]);
+    if (mx) atomicMax(&longest, mx);
+    __syncthreads();
+    const uint32_t bar = longest / 2u + 1u;  // hot: a wave there lived more than half as long as the longest of the frame
+    int hot = 0;
+    for (int i = b; i < e; i++) hot += heat[i] >= bar;
+    part[t] = hot;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    if (t == 1023) total_hot = part[1023];
+    __syncthreads();
+    int at_hot = part[t] - hot;                     // hot super-tiles before this thread's range
+    int at_cold = total_hot + (b < n ? b : n) - at_hot;  // cold ones go behind all hot ones, in index order
+    for (int i = b; i < e; i++) {
+        if (heat[i] >= bar)
+            order[at_hot++] = i;
+        else
+            order[at_cold++] = i;
+    }
+}
+
 // ---- large scenes: per-lane ordered traversal of the re-treed leaves, stacks in LDS ----------------
 // Same pixel mapping as k_render; dynamic LDS = BLOCK_WAVES * 64 lanes * leaf_levels dwords.
 #ifndef RT_BVH_WAVES_PER_EU
@@ -851,14 +913,18 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 #ifndef RT_COOP_WAVES_PER_EU
 #define RT_COOP_WAVES_PER_EU 4
 #endif
-template <bool UNB, bool COOP>
+template <bool UNB, bool COOP, bool HEAT = false>
 __global__ __launch_bounds__(64 * BLOCK_WAVES)
     __attribute__((amdgpu_waves_per_eu(COOP ? RT_COOP_WAVES_PER_EU : RT_BVH_WAVES_PER_EU, 8))) void k_render_bvh(const RenderArgs a) {
     int tx, ty, block = blockIdx.x;
     float cam[14];
     PriorityRect prio;
     const int frame = select_frame(a, &block, cam, &prio);
-    const bool in_image = block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, prio, &tx, &ty);
+    int super_idx = 0;
+    unsigned long long heat_t0 = 0;
+    if (HEAT) heat_t0 = __builtin_amdgcn_s_memrealtime();
+    const bool in_image = HEAT ? block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, prio, &tx, &ty, a.order, &super_idx)
+                               : block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, prio, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
     const int r = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);
@@ -896,6 +962,10 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES)
         if (a.primary_id) a.primary_id[i] = diag[2];
         if (a.rgb) a.rgb[3 * i] = (float)diag[3];
 #endif
+    }
+    if (HEAT && in_image) {  // this wave's lifetime in 10 ns ticks, if it was a long one: its super-tile starts earlier next time
+        const uint32_t ticks = (uint32_t)(__builtin_amdgcn_s_memrealtime() - heat_t0);
+        if (ticks >= RT_HEAT_MIN_TICKS && (threadIdx.x & 63) == 0) atomicMax(&a.heat_out[super_idx], ticks);
     }
 }
 

@@ -532,3 +532,24 @@ def test_cooperative_kernel_with_many_lights(n_lights, rt_mode, scene_of):
     _set_mode(rt, 2)
     plain = _render(rt, many, cam, 6)
     assert np.array_equal(out["rgb"].view(np.uint32), plain["rgb"].view(np.uint32))
+
+
+@pytest.mark.parametrize("mode,label", [(2, "bvh"), (5, "bvh+coop-shadows")])
+def test_order_by_the_previous_frame_changes_no_pixel(mode, label, rt_mode, scene_of):
+    """Single frames of a scene whose root box spans the view (no priority columns) and whose paths may bounce three
+    times or more are dealt out in an order ranked from the previous launch's wave lifetimes (k_rank_supers).  The
+    first frame has no marks, the next ones do; a camera cut and a change of size leave stale marks behind.  Every
+    frame must equal the reference-order kernel's, whatever order its tiles were rendered in."""
+    from raytracing_amd import host
+    rt = rt_mode
+    sc = scene_of("TestScene1")
+    _set_mode(rt, mode)
+    rt.SendPrimitivesToShader(sc)
+    cams = [sc.camera_for(320, 180)] * 3 + [host.camera_orbit(40, 96, 320, 180)] * 2 + [sc.camera_for(200, 120)] * 2 + \
+           [sc.camera_for(320, 180)]
+    for k, cam in enumerate(cams):
+        rt.PrepareRenderOpenGL(cam)
+        out = rt.RenderGL(10)
+        ref = rt.RenderGL(10, stats=True)            # (stats: the reference-order kernel)
+        for plane in ("rgb", "primary_id", "final_id", "rgba8"):
+            assert np.array_equal(out[plane].view(np.uint8), ref[plane].view(np.uint8)), (label, k, plane)
