@@ -867,38 +867,39 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 #define RT_HEAT_MIN_TICKS 3000u  // waves that lived 30 us or longer report
 #endif
 __global__ __launch_bounds__(1024) void k_rank_supers(const uint32_t* __restrict__ heat, int n, int32_t* __restrict__ order) {
-    __shared__ int part[1024];
-    __shared__ int total_hot;
+    // 16 waves, each owns a contiguous run of super-tiles (a multiple of 64 long) and walks it 64 at a time: a ballot
+    // gives every lane its rank among the hot ones of the step.  Three barriers in all.
     __shared__ uint32_t longest;
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = t * per, e = min(n, b + per);
+    __shared__ int wave_hot[16];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int run = ((n + 16 * 64 - 1) / (16 * 64)) * 64;
+    const int b = min(n, wave * run), e = min(n, b + run);
     if (t == 0) longest = 0u;
     __syncthreads();
     uint32_t mx = 0u;
-    for (int i = b; i < e; i++) mx = max(mx, heat[i]);
+    for (int i = b + lane; i < e; i += 64) mx = max(mx, heat[i]);
     if (mx) atomicMax(&longest, mx);
     __syncthreads();
     const uint32_t bar = longest / 2u + 1u;  // hot: a wave there lived more than half as long as the longest of the frame
-    int hot = 0;
-    for (int i = b; i < e; i++) hot += heat[i] >= bar;
-    part[t] = hot;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
-        const int v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    int hot = 0;                              // (wave-uniform) hot super-tiles of this wave's run
+    for (int i0 = b; i0 < e; i0 += 64) {
+        const int i = i0 + lane;
+        hot += __popcll(__ballot(i < e && heat[i] >= bar));
     }
-    if (t == 1023) total_hot = part[1023];
+    if (lane == 0) wave_hot[wave] = hot;
     __syncthreads();
-    int at_hot = part[t] - hot;                     // hot super-tiles before this thread's range
-    int at_cold = total_hot + (b < n ? b : n) - at_hot;  // cold ones go behind all hot ones, in index order
-    for (int i = b; i < e; i++) {
-        if (heat[i] >= bar)
-            order[at_hot++] = i;
-        else
-            order[at_cold++] = i;
+    int hot_before = 0, total_hot = 0;
+    for (int w = 0; w < 16; w++) {
+        hot_before += w < wave ? wave_hot[w] : 0;
+        total_hot += wave_hot[w];
+    }
+    for (int i0 = b; i0 < e; i0 += 64) {
+        const int i = i0 + lane;
+        const bool is_hot = i < e && heat[i] >= bar;
+        const unsigned long long m = __ballot(is_hot);
+        const int rank = hot_before + __popcll(m & ((1ull << lane) - 1ull));  // hot super-tiles before i
+        if (i < e) order[is_hot ? rank : total_hot + (i - rank)] = i;           // cold ones behind all hot ones, in index order
+        hot_before += __popcll(m);
     }
 }
 
