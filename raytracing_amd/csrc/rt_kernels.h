@@ -866,7 +866,9 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
 #ifndef RT_HEAT_MIN_TICKS
 #define RT_HEAT_MIN_TICKS 3000u  // waves that lived 30 us or longer report
 #endif
-__global__ __launch_bounds__(1024) void k_rank_supers(const uint32_t* __restrict__ heat, int n, int32_t* __restrict__ order) {
+// (clears `next`, the words this launch's waves will report into, on the way: one stream operation less per frame)
+__global__ __launch_bounds__(1024) void k_rank_supers(const uint32_t* __restrict__ heat, int n, int32_t* __restrict__ order,
+                                                      uint32_t* __restrict__ next) {
     // 16 waves, each owns a contiguous run of super-tiles (a multiple of 64 long) and walks it 64 at a time: a ballot
     // gives every lane its rank among the hot ones of the step.  Three barriers in all.
     __shared__ uint32_t longest;
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(1024) void k_rank_supers(const uint32_t* __restrict
     if (t == 0) longest = 0u;
     __syncthreads();
     uint32_t mx = 0u;
-    for (int i = b + lane; i < e; i += 64) mx = max(mx, heat[i]);
+    for (int i = b + lane; i < e; i += 64) mx = max(mx, heat[i]), next[i] = 0u;
     if (mx) atomicMax(&longest, mx);
     __syncthreads();
     const uint32_t bar = longest / 2u + 1u;  // hot: a wave there lived more than half as long as the longest of the frame

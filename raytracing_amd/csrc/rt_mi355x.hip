@@ -971,10 +971,12 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
             if ((rc = chain_begin(ctx, st)) != RT_OK) return rc;  // the marks and the table belong to one launch at a time
             const int prev = ctx->heat_cur, cur = prev ^ 1;
             if (same) {
-                hipLaunchKernelGGL(k_rank_supers, dim3(1), dim3(1024), 0, st, (const uint32_t*)ctx->heat[prev].p, n_pad, (int32_t*)ctx->order.p);
+                hipLaunchKernelGGL(k_rank_supers, dim3(1), dim3(1024), 0, st, (const uint32_t*)ctx->heat[prev].p, n_pad, (int32_t*)ctx->order.p,
+                                   (uint32_t*)ctx->heat[cur].p);
                 a.order = (const int32_t*)ctx->order.p;
+            } else {
+                HIP_TRY(ctx, hipMemsetAsync(ctx->heat[cur].p, 0, (size_t)n_pad * 4, st));
             }
-            HIP_TRY(ctx, hipMemsetAsync(ctx->heat[cur].p, 0, (size_t)n_pad * 4, st));
             a.heat_out = (uint32_t*)ctx->heat[cur].p;
             ctx->heat_cur = cur, ctx->heat_valid = true;
             std::memcpy(ctx->heat_key, key, sizeof key);
