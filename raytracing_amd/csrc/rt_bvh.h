@@ -32,12 +32,53 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
 #include "rt_flatten.h"
 
 namespace rtb {
+
+// A few worker threads whose failures come back to the caller.  A body that throws (std::bad_alloc on a
+// multi-million-primitive scene) is caught in its own thread; every thread is joined -- also when the caller's own
+// share of the work throws, or when a thread cannot be started -- and finish() rethrows the first failure on the
+// calling thread, where the C ABI turns it into an error code (a joinable std::thread that is destroyed, or an
+// exception that leaves a thread's body, would end the host process instead).
+class Crew {
+public:
+    template <class F>
+    void start(F f) {
+        pool_.emplace_back([this, f]() mutable {
+            try {
+                f();
+            } catch (...) {
+                std::lock_guard<std::mutex> hold(mu_);
+                if (!err_) err_ = std::current_exception();
+            }
+        });
+    }
+    void finish() {
+        join();
+        if (err_) {
+            const std::exception_ptr e = err_;
+            err_ = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+    ~Crew() { join(); }
+
+private:
+    void join() {
+        for (std::thread& t : pool_)
+            if (t.joinable()) t.join();
+        pool_.clear();
+    }
+    std::vector<std::thread> pool_;
+    std::exception_ptr err_;
+    std::mutex mu_;
+};
 
 struct Node {
     float lo[3][2];  // [axis][child]   (float4 0 and the first half of float4 1)
@@ -154,10 +195,10 @@ struct Builder {
         const int helpers = (forks > 0 && n >= SWEEP_MIN) ? (1 << std::min(forks, 4)) : 1;
         auto sweep = [&](auto&& body) {  // body(thread index, first, last)
             if (helpers == 1) return body(0, b, e);
-            std::vector<std::thread> pool;
-            for (int t = 1; t < helpers; t++) pool.emplace_back([&, t] { body(t, b + n * t / helpers, b + n * (t + 1) / helpers); });
+            Crew crew;
+            for (int t = 1; t < helpers; t++) crew.start([&, t] { body(t, b + n * t / helpers, b + n * (t + 1) / helpers); });
             body(0, b, b + n / helpers);
-            for (std::thread& th : pool) th.join();
+            crew.finish();
         };
         Box cb;  // centroid bounds
         cb.reset();
@@ -248,9 +289,10 @@ struct Builder {
         uint32_t rl, rr;
         const uint32_t right_base = base + (uint32_t)(mid - b);  // 1 for this node + (mid - b - 1) of the left subtree
         if (forks > 0 && n >= FORK_MIN) {
-            std::thread left([&] { rl = build(b, mid, level + 1, &l, base + 1, forks - 1); });
+            Crew crew;
+            crew.start([&] { rl = build(b, mid, level + 1, &l, base + 1, forks - 1); });
             rr = build(mid, e, level + 1, &r, right_base, forks - 1);
-            left.join();
+            crew.finish();
         } else {
             rl = build(b, mid, level + 1, &l, base + 1, 0);
             rr = build(mid, e, level + 1, &r, right_base, 0);
@@ -471,10 +513,10 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
         fill(0, n_nodes, items, sphere_items);
     } else {
         std::vector<std::vector<detail::Item>> part(n_threads), sphere_part(n_threads);
-        std::vector<std::thread> pool;
+        Crew crew;
         for (int t = 0; t < n_threads; t++)
-            pool.emplace_back([&, t] { fill(n_nodes * t / n_threads, n_nodes * (t + 1) / n_threads, part[t], sphere_part[t]); });
-        for (std::thread& th : pool) th.join();
+            crew.start([&, t] { fill(n_nodes * t / n_threads, n_nodes * (t + 1) / n_threads, part[t], sphere_part[t]); });
+        crew.finish();
         for (int t = 0; t < n_threads; t++) {
             items.insert(items.end(), part[t].begin(), part[t].end());
             sphere_items.insert(sphere_items.end(), sphere_part[t].begin(), sphere_part[t].end());
@@ -568,9 +610,9 @@ inline bool quantize(const Bvh& in, QBvh* out) {
     if (n_threads == 1) {
         run(0, n);
     } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; t++) pool.emplace_back([&, t] { run(n * t / n_threads, n * (t + 1) / n_threads); });
-        for (std::thread& th : pool) th.join();
+        Crew crew;
+        for (int t = 0; t < n_threads; t++) crew.start([&, t] { run(n * t / n_threads, n * (t + 1) / n_threads); });
+        crew.finish();
     }
     return true;
 }

@@ -131,6 +131,23 @@ int hip_fail(rt_ctx* ctx, hipError_t e, const char* what) {
     return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE,
                 std::string(what) + ": " + hipGetErrorString(e));
 }
+// No exception crosses the ABI (rt_mi355x.h): host-side preparation allocates (std::bad_alloc on a scene that does not
+// fit host memory) and runs worker threads (rt_bvh.h Crew rethrows their failures here).
+template <class F>
+int no_throw(rt_ctx* ctx, std::string* msg, F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        if (msg) *msg = "out of host memory";
+        return fail(ctx, RT_ERR_OUT_OF_MEMORY, "out of host memory");
+    } catch (const std::exception& e) {
+        if (msg) *msg = std::string("internal error: ") + e.what();
+        return fail(ctx, RT_ERR_DEVICE, std::string("internal error: ") + e.what());
+    } catch (...) {
+        if (msg) *msg = "internal error";
+        return fail(ctx, RT_ERR_DEVICE, "internal error");
+    }
+}
 #define HIP_TRY(ctx, expr)                                     \
     do {                                                       \
         hipError_t e_ = (expr);                                \
@@ -267,7 +284,9 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st, bool noal
         a.blocked = (unsigned char*)ctx->wf_blocked.p;
         a.counters = (uint32_t*)ctx->wf_counters.p;
     }
-    if ((rc = chain_begin(ctx, st))) return rc;
+    // (noalloc: no event work at all -- the caller orders its calls on one GPU, rt_mi355x.h -- so the whole render is
+    // memset + kernel launches on `st` and can be recorded into a HIP graph)
+    if (!noalloc && (rc = chain_begin(ctx, st))) return rc;
     // the only part of the state that must start at zero (the array keeps the previous call's contents)
     HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, lay.n_counters * 4, st));
     const int trace_grid = ctx->n_cus * ctx->wf_waves_per_cu;
@@ -286,7 +305,7 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st, bool noal
         hipLaunchKernelGGL(k_wf_shade, dim3(shade_grid), dim3(256), 0, st, a);
     }
     HIP_TRY(ctx, hipGetLastError());
-    return chain_end(ctx, st);
+    return noalloc ? (int)RT_OK : chain_end(ctx, st);
 }
 
 }  // namespace
@@ -574,10 +593,23 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     return RT_OK;
 }
 
+static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
+                        const void* triangles, int n_triangles, const float* accel, int64_t accel_len,
+                        const float* lights, int lights_len);
 int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
                     const void* triangles, int n_triangles, const float* accel, int64_t accel_len,
                     const float* lights, int lights_len) {
     if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    const int rc = no_throw(ctx, nullptr, [&] {
+        return upload_scene(ctx, spheres, n_spheres, planes, n_planes, triangles, n_triangles, accel, accel_len, lights, lights_len);
+    });
+    // the copy of the accel array the GPU flatten worked on is not needed once the scene is up (or refused)
+    if (ctx->accel_tmp.p && hipSetDevice(ctx->device) == hipSuccess) release(ctx->accel_tmp);
+    return rc;
+}
+static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
+                        const void* triangles, int n_triangles, const float* accel, int64_t accel_len,
+                        const float* lights, int lights_len) {
     if (n_spheres < 0 || n_planes < 0 || n_triangles < 0 || accel_len < 0 || lights_len < 0 || lights_len % 6 != 0)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "negative count or lights_len not a multiple of 6");
     if ((n_spheres && !spheres) || (n_planes && !planes) || (n_triangles && !triangles) || (accel_len && !accel) ||
@@ -615,7 +647,13 @@ int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_t
     int rc = (accel_len < 0 || n_spheres < 0 || n_triangles < 0 || (accel_len && !accel)) ? RT_ERR_INVALID_ARGUMENT
                                                                                          : RT_OK;
     if (rc != RT_OK) msg = "negative size or null array";
-    if (rc == RT_OK) rc = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &flat, &msg);
+    rtb::Bvh bvh;
+    if (rc == RT_OK)
+        rc = no_throw(nullptr, &msg, [&] {
+            const int r = rtf::flatten(accel, accel_len, n_spheres, n_triangles, &flat, &msg);
+            if (r == RT_OK && info && flat.nested) rtb::build(flat, &bvh);
+            return r;
+        });
     if (err && err_cap) {
         std::strncpy(err, msg.c_str(), err_cap - 1);
         err[err_cap - 1] = 0;
@@ -630,8 +668,6 @@ int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_t
             (int64_t)(flat.nodes.size() * 32 + flat.tri_slot_id.size() * 48 + flat.sphere_slot_id.size() * 16);
         info->flags = flat.nested ? RT_SCENE_NESTED : 0;  // RT_SCENE_CULL needs the primitives: upload only
         if (flat.nested) {
-            rtb::Bvh bvh;
-            rtb::build(flat, &bvh);
             info->bvh_nodes = (int64_t)bvh.nodes.size();
             info->bvh_levels = bvh.levels;
         }
@@ -649,19 +685,19 @@ int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, in
         msg = "negative size or null array";
     }
     rtp::Prepared prep;
-    if (rc == RT_OK) {
-        rtp::Options opt;
-        opt.tight_min_nodes = tight_min_nodes;
-        rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
-                          accel_len, opt, &prep, &msg);
-    }
-    if (rc == RT_OK) {
-        msg = rtp::verify_tree(prep.bvh, nullptr, nullptr, nullptr);
-        if (msg.empty())
-            msg = rtp::verify_tree(prep.tight, &prep, (const unsigned char*)spheres, (const unsigned char*)triangles);
-        if (msg.empty()) msg = rtp::verify_quantized(prep.tight, prep.tight_q);
-        if (!msg.empty()) rc = RT_ERR_DEVICE;  // an internal inconsistency, never expected
-    }
+    if (rc == RT_OK)
+        rc = no_throw(nullptr, &msg, [&] {
+            rtp::Options opt;
+            opt.tight_min_nodes = tight_min_nodes;
+            int r = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
+                                 accel_len, opt, &prep, &msg);
+            if (r != RT_OK) return r;
+            msg = rtp::verify_tree(prep.bvh, nullptr, nullptr, nullptr);
+            if (msg.empty())
+                msg = rtp::verify_tree(prep.tight, &prep, (const unsigned char*)spheres, (const unsigned char*)triangles);
+            if (msg.empty()) msg = rtp::verify_quantized(prep.tight, prep.tight_q);
+            return msg.empty() ? (int)RT_OK : (int)RT_ERR_DEVICE;  // an internal inconsistency, never expected
+        });
     if (err && err_cap) {
         std::strncpy(err, msg.c_str(), err_cap - 1);
         err[err_cap - 1] = 0;

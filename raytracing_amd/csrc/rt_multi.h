@@ -29,12 +29,19 @@ struct Rccl {
     std::string error;
     bool load() {
         if (lib) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
+        // RT_RCCL_LIBRARY names the library to load instead (tests use it to force the failure path)
+        const char* forced = std::getenv("RT_RCCL_LIBRARY");
+        if (forced && *forced) {
+            lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (lib) break;
+            }
         }
         if (!lib) {
-            error = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?");
+            const char* e = dlerror();  // (one call: dlerror clears the state it reports)
+            error = std::string("cannot load librccl.so: ") + (e ? e : "?");
             return false;
         }
         auto sym = [&](const char* n) {
@@ -148,11 +155,16 @@ static int multi_gather_plane(rt_ctx* root, size_t elem, int w, int h, const std
         // grouped: every device sends its chunk to rank 0, rank 0 receives n chunks (its own included: a
         // send to self inside a group is a local copy), all progressing concurrently on their own links
         NCCL_TRY(root, g_rccl.GroupStart());
-        for (int d = 0; d < m->n; d++) {
-            NCCL_TRY(root, g_rccl.Send(src[d], chunk, ncclUint8, 0, m->comm[d], m->stream[d]));
-            NCCL_TRY(root, g_rccl.Recv(g + chunk * d, chunk, ncclUint8, d, m->comm[0], m->stream[0]));
+        ncclResult_t bad = ncclSuccess;
+        const char* what = "";
+        for (int d = 0; d < m->n && bad == ncclSuccess; d++) {
+            if ((bad = g_rccl.Send(src[d], chunk, ncclUint8, 0, m->comm[d], m->stream[d])) != ncclSuccess) what = "ncclSend";
+            else if ((bad = g_rccl.Recv(g + chunk * d, chunk, ncclUint8, d, m->comm[0], m->stream[0])) != ncclSuccess) what = "ncclRecv";
         }
-        NCCL_TRY(root, g_rccl.GroupEnd());
+        // a group that was opened is always closed, whatever happened inside it
+        const ncclResult_t end = g_rccl.GroupEnd();
+        if (bad != ncclSuccess) return nccl_fail(root, bad, what);
+        if (end != ncclSuccess) return nccl_fail(root, end, "ncclGroupEnd");
     } else {
         for (int d = 0; d < m->n; d++) {
             HIP_TRY(root, hipStreamWaitEvent(m->stream[0], m->done[d], 0));
@@ -162,9 +174,26 @@ static int multi_gather_plane(rt_ctx* root, size_t elem, int w, int h, const std
     return rt_unpermute_bands(root, g, out, (int)elem, w, h, MULTI_BAND_ROWS, m->n, m->stream[0]);
 }
 
-// rt_render on a multi-GPU context.
+static int multi_render_impl(rt_ctx* root, const float* camera, int max_bounces, float* rgb, uint8_t* rgba8, int32_t* primary_id,
+                             int32_t* final_id, rt_stats* stats);
+// rt_render on a multi-GPU context.  Whatever goes wrong on the way, the call does not return while any device's
+// stream still has work of this frame in flight (the caller may free or reuse its arrays at once).
 static int multi_render(rt_ctx* root, const float* camera, int max_bounces, float* rgb, uint8_t* rgba8, int32_t* primary_id,
                         int32_t* final_id, rt_stats* stats) {
+    const int rc = multi_render_impl(root, camera, max_bounces, rgb, rgba8, primary_id, final_id, stats);
+    if (rc != RT_OK) {
+        rt_multi* m = root->multi;
+        const std::string first = root->error;  // keep the first failure's message
+        for (int d = 0; d < m->n; d++)
+            if (m->sub[d] && m->stream[d] && hipSetDevice(m->sub[d]->device) == hipSuccess) (void)hipStreamSynchronize(m->stream[d]);
+        (void)hipGetLastError();
+        (void)hipSetDevice(root->device);
+        root->error = first;
+    }
+    return rc;
+}
+static int multi_render_impl(rt_ctx* root, const float* camera, int max_bounces, float* rgb, uint8_t* rgba8, int32_t* primary_id,
+                             int32_t* final_id, rt_stats* stats) {
     rt_multi* m = root->multi;
     int w, h;
     if (camera_size(camera, &w, &h) != RT_OK)

@@ -113,13 +113,13 @@ inline bool check_containment(const rtf::Flat& flat, const unsigned char* sphere
     if (n_threads == 1) return check_containment_range(flat, spheres, triangles, slack, max_extent, 0, n, tri_unbounded, unbounded_leaves);
     std::vector<std::vector<int32_t>> found(n_threads);
     std::vector<char> ok(n_threads, 1);
-    std::vector<std::thread> pool;
+    rtb::Crew crew;
     for (int t = 0; t < n_threads; t++)
-        pool.emplace_back([&, t] {
+        crew.start([&, t] {
             ok[t] = check_containment_range(flat, spheres, triangles, slack, max_extent, n * t / n_threads, n * (t + 1) / n_threads,
                                             tri_unbounded, &found[t]) ? 1 : 0;
         });
-    for (std::thread& th : pool) th.join();
+    crew.finish();
     for (int t = 0; t < n_threads; t++) {
         if (!ok[t]) return false;
         unbounded_leaves->insert(unbounded_leaves->end(), found[t].begin(), found[t].end());  // ranges in order: sorted
@@ -171,9 +171,9 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
     out->pad_tri = out->tight_e * (1.0f / 16384.0f), out->pad_sphere = out->tight_e * (1.0f / 256.0f);
     const bool want_tight = opt.build_tight && out->contained && flat.nested && (int64_t)flat.nodes.size() >= opt.tight_min_nodes &&
                             max_extent <= 1e6f;
-    std::thread tight_builder;
+    rtb::Crew tight_builder;  // (joined whatever happens below; a failure in either builder is rethrown by finish())
     if (want_tight)
-        tight_builder = std::thread([&] {
+        tight_builder.start([&] {
             rtb::TightInput in;
             in.tris = triangles, in.spheres = spheres;
             in.pad_tri = out->pad_tri, in.pad_sphere = out->pad_sphere;
@@ -183,7 +183,7 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
     if (flat.nested) rtb::build(flat, &out->bvh);
     lap("re-tree the leaves (SAH)");
     if (want_tight) {
-        tight_builder.join();
+        tight_builder.finish();
         if (out->bvh.nodes.empty() || out->tight.levels > rtb::MAX_LEVELS) {  // (no leaf holds a primitive / too deep)
             out->tight = rtb::Bvh();
             out->tri_slot_leaf.clear(), out->sphere_slot_leaf.clear();

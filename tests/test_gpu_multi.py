@@ -53,3 +53,24 @@ def test_multi_context_argument_errors():
     n, r = C.c_int(), C.c_int()
     with RayTracer(0) as one:
         assert one.multi_info() == {"n_devices": 1, "uses_rccl": False}
+
+
+def test_rccl_that_cannot_be_loaded_is_an_error_code_not_a_crash():
+    """the loader formed its message from two dlerror() calls (the second returns NULL).  A fresh
+    process whose RCCL is forced to a missing file (RT_RCCL_LIBRARY) must get RT_ERR_DEVICE from rt_create_multi --
+    for every distinct-device list, n = 1 included -- and go on working."""
+    import os
+    import subprocess
+    import sys
+    code = ("import ctypes as C, torch\n"
+            "from raytracing_amd import _native as N, RayTracer\n"
+            "lib = N.device_lib(); ctx = C.c_void_p(); ids = (C.c_int * 1)(0)\n"
+            "rc = lib.rt_create_multi(ids, 1, C.byref(ctx))\n"
+            "assert rc == -4 and not ctx, rc\n"
+            "with RayTracer(0) as one: assert one.multi_info()['n_devices'] == 1\n"
+            "print('survived')\n")
+    env = dict(os.environ, RT_RCCL_LIBRARY="/nonexistent/librccl-missing.so")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "survived" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    assert "cannot load librccl.so" in p.stderr

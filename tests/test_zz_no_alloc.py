@@ -80,3 +80,38 @@ def test_noalloc_megakernel_path_and_size_limit(rt, scene_of):
         _same(a, b, "1280x720")
     finally:
         rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)
+
+
+def test_noalloc_render_can_be_recorded_into_a_graph_and_replayed(rt, scene_of):
+    """The entry point does no allocation and no event work, so a caller under stream capture can record it: one
+    render of the staged pipeline (memset of the counters + 3 kernels per bounce) captured into a graph, replayed
+    twice into buffers that were overwritten in between, equals rt_render_device."""
+    sc = scene_of("Soup", [8000, 80, 8])
+    rt.SendPrimitivesToShader(sc)
+    rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_WAVEFRONT)
+    try:
+        w, h, depth = 200, 120, 4
+        cam = sc.camera_for(w, h)
+        ref = _render(rt, rt.render_device, cam, depth, w, h)
+        dev = torch.device("cuda", 0)
+        out = {"rgb": torch.zeros((h, w, 3), dtype=torch.float32, device=dev),
+               "rgba8": torch.zeros((h, w, 4), dtype=torch.uint8, device=dev),
+               "primary_id": torch.zeros((h, w), dtype=torch.int32, device=dev),
+               "final_id": torch.zeros((h, w), dtype=torch.int32, device=dev),
+               "bounces": torch.zeros((h, w), dtype=torch.int32, device=dev)}
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=torch.cuda.Stream()):
+            rt.render_device_noalloc(cam, depth, stream=torch.cuda.current_stream().cuda_stream,
+                                     **{k: v.data_ptr() for k, v in out.items()})
+        for rep in range(2):
+            for v in out.values():
+                v.fill_(77)
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            _same({k: v.cpu().numpy() for k, v in out.items()}, ref, f"graph replay {rep}")
+        # and the context still renders normally afterwards (nothing was left waiting on a captured event)
+        _same(_render(rt, rt.render_device, cam, depth, w, h), ref, "after the graph")
+    finally:
+        rt.set_option(rt.OPTION_TRAVERSAL, rt.TRAVERSAL_AUTO)
