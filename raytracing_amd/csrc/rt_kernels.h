@@ -675,6 +675,36 @@ __device__ __forceinline__ uint32_t quantise(float v) {
 struct PriorityRect {
     int x0, y0, x1, y1;
 };
+// Division of an index below 2^31 by a divisor that is fixed at launch: n / d = (n * m) >> p with p = 31 + ceil(log2 d),
+// m = ceil(2^p / d) < 2^32 (exact for every n < 2^31: m d - 2^p < d <= 2^(p-31), so the excess n (m d - 2^p) stays below
+// 2^p).  The block -> tile mapping of every wave divides by five launch constants; as generic 32-bit divisions each
+// costs ~30 instructions, among them a v_rcp on a wave-uniform value and a v_readfirstlane round trip (the prologue
+// of a wave was ~480 instructions, three quarters of what a sky tile costs); this form is a 64-bit scalar multiply
+// and a shift.  The host fills these in (make_fastdiv).
+struct FastDiv {
+    uint32_t d, m, p;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    if (d == 0) d = 1;
+    uint32_t l = 0;
+    while (l < 32 && ((uint64_t)1 << l) < d) l++;
+    f.d = d, f.p = 31 + l;
+    f.m = (uint32_t)((((uint64_t)1 << f.p) + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) { return (uint32_t)(((unsigned long long)n * f.m) >> f.p); }
+// the divisors of a launch's block -> tile mapping (block_to_tile, priority_super, select_frame, global_row)
+struct TileMap {
+    FastDiv per;     // tiles per super-tile (supertile^2)
+    FastDiv st;      // super-tile edge in tiles
+    FastDiv sxn;     // super-tiles per row of them
+    FastDiv frames;  // frames of a batched launch
+    FastDiv band;    // rows per band (band-sharded frames)
+};
+struct PriorityDivs {
+    FastDiv rw, side;  // width of the priority rectangle / of the rest of a row beside it, in super-tiles
+};
 constexpr int MAX_BATCH = 8;  // frames one launch of the megakernels can render (rt_render_frames_device)
 struct RenderArgs {
     DevScene scene;
@@ -684,6 +714,8 @@ struct RenderArgs {
     int blocks_per_frame;
     unsigned long long frame_stride;    // pixels between consecutive frames in every output plane
     PriorityRect prio[MAX_BATCH];       // per frame: super-tiles dealt out first (block_to_tile)
+    PriorityDivs prio_div[MAX_BATCH];
+    TileMap map;
     int max_bounces;
     int width, height;   // full frame
     int local_rows;      // rows this launch renders
@@ -709,30 +741,40 @@ struct RenderArgs {
 // the camera is picked with compile-time indices only (a dynamic index into the by-value argument struct
 // would send the whole struct to scratch memory).  Returns the frame; *block becomes the block index
 // inside the frame.
-__device__ __forceinline__ int select_frame(const RenderArgs& a, int* block, float cam[14], PriorityRect* prio) {
+__device__ __forceinline__ int select_frame(const RenderArgs& a, int* block, float cam[14], PriorityRect* prio, PriorityDivs* pdiv) {
     int f = 0;
-    if (a.n_frames > 1) {
+    if (a.n_frames > 1) {  // (wave-uniform)
         // Groups of 8 consecutive blocks (one per XCD) go round the frames: every frame's priority columns
         // start at once, and every frame is spread over all XCDs.  (One frame after the other: a rank's share
         // of an 8-GPU step 0.284 ms, interleaved 0.216; block-by-block interleave would pin frame f to XCD f.)
-        const int g = *block >> 3;
-        f = g % a.n_frames;
-        *block = ((g / a.n_frames) << 3) | (*block & 7);
+        const uint32_t g = (uint32_t)*block >> 3;
+        const uint32_t round = fd_div(g, a.map.frames);
+        f = (int)(g - round * a.map.frames.d);
+        *block = (int)((round << 3) | ((uint32_t)*block & 7u));
     }
+    // The frame's camera and priority columns come straight from the kernel-argument segment at a wave-uniform
+    // offset (scalar loads).  Indexing the by-value argument struct with a run-time index would send the whole
+    // struct to scratch memory, and picking with compile-time indices only -- a chain of selects over the eight
+    // frames for each of the 34 words, the earlier form -- cost every wave ~300 scalar instructions.  The render
+    // kernels take RenderArgs as their only argument, so the struct starts at offset 0 of the segment; cam and
+    // more_cams are adjacent arrays of 14 floats.
+    static_assert(offsetof(RenderArgs, more_cams) == offsetof(RenderArgs, cam) + 14 * sizeof(float), "cameras must be contiguous");
+    typedef const __attribute__((address_space(4))) char KChar;
+    typedef const __attribute__((address_space(4))) float KFloat;
+    typedef const __attribute__((address_space(4))) int KInt;
+    typedef const __attribute__((address_space(4))) uint32_t KU32;
+    KChar* const ka = (KChar*)__builtin_amdgcn_kernarg_segment_ptr();
+    KFloat* const cams = (KFloat*)(ka + offsetof(RenderArgs, cam)) + 14 * f;
 #pragma unroll
-    for (int k = 0; k < 14; k++) {
-        float v = a.cam[k];
-#pragma unroll
-        for (int q = 1; q < MAX_BATCH; q++) v = (f == q) ? a.more_cams[q - 1][k] : v;
-        cam[k] = v;
-    }
-    PriorityRect pr = a.prio[0];
-#pragma unroll
-    for (int q = 1; q < MAX_BATCH; q++) {
-        pr.x0 = (f == q) ? a.prio[q].x0 : pr.x0, pr.y0 = (f == q) ? a.prio[q].y0 : pr.y0;
-        pr.x1 = (f == q) ? a.prio[q].x1 : pr.x1, pr.y1 = (f == q) ? a.prio[q].y1 : pr.y1;
-    }
-    *prio = pr;
+    for (int k = 0; k < 14; k++) cam[k] = cams[k];
+    KInt* const prs = (KInt*)(ka + offsetof(RenderArgs, prio)) + 4 * f;
+    PriorityRect pr;
+    pr.x0 = prs[0], pr.y0 = prs[1], pr.x1 = prs[2], pr.y1 = prs[3];
+    static_assert(sizeof(PriorityRect) == 16 && sizeof(PriorityDivs) == 24, "layout of the per-frame launch constants");
+    KU32* const pds = (KU32*)(ka + offsetof(RenderArgs, prio_div)) + 6 * f;
+    PriorityDivs pd;
+    pd.rw.d = pds[0], pd.rw.m = pds[1], pd.rw.p = pds[2], pd.side.d = pds[3], pd.side.m = pds[4], pd.side.p = pds[5];
+    *prio = pr, *pdiv = pd;
     return f;
 }
 
@@ -746,7 +788,8 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& a, int frame, int 
 }
 // local row (band-sharded frames, rt_mi355x.h) -> global row
 __device__ __forceinline__ int global_row(const RenderArgs& a, int r) {
-    return ((r / a.band_rows) * a.world + a.rank) * a.band_rows + r % a.band_rows;
+    const uint32_t band = fd_div((uint32_t)r, a.map.band);  // r / band_rows
+    return (int)((band * (uint32_t)a.world + (uint32_t)a.rank) * (uint32_t)a.band_rows + ((uint32_t)r - band * (uint32_t)a.band_rows));
 }
 
 // Block -> tile mapping.  Blocks b and b+8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md);
@@ -756,47 +799,50 @@ __device__ __forceinline__ int global_row(const RenderArgs& a, int r) {
 // every slot gets super-tiles from all over the image (so sky, floor and mesh work is balanced
 // across XCDs -- one contiguous run of tiles per XCD left the sky XCDs idle: 30 % wave-slot use).
 // Returns false for the padding blocks of a partial super-tile.
-__device__ __forceinline__ void priority_super(int k, int sx_n, PriorityRect pr, int* sx, int* sy) {
+__device__ __forceinline__ void priority_super(uint32_t k, const FastDiv& sxn, const PriorityRect& pr, const PriorityDivs& pd,
+                                               uint32_t* sx, uint32_t* sy) {
     const int rw = pr.x1 - pr.x0 + 1, rh = pr.y1 - pr.y0 + 1;
     if (rw <= 0 || rh <= 0) {
-        *sx = k % sx_n, *sy = k / sx_n;
+        *sy = fd_div(k, sxn), *sx = k - *sy * sxn.d;
         return;
     }
-    const int n_rect = rw * rh;
+    const uint32_t n_rect = (uint32_t)(rw * rh);
     if (k < n_rect) {
-        *sx = pr.x0 + k % rw, *sy = pr.y0 + k / rw;
+        const uint32_t row = fd_div(k, pd.rw);
+        *sx = (uint32_t)pr.x0 + (k - row * pd.rw.d), *sy = (uint32_t)pr.y0 + row;
         return;
     }
     k -= n_rect;
-    const int below = pr.y0 * sx_n, side = sx_n - rw, mid = rh * side;
+    const uint32_t below = (uint32_t)pr.y0 * sxn.d, side = sxn.d - (uint32_t)rw, mid = (uint32_t)rh * side;
     if (k < below) {
-        *sx = k % sx_n, *sy = k / sx_n;
+        *sy = fd_div(k, sxn), *sx = k - *sy * sxn.d;
     } else if (k - below < mid) {  // side > 0 here
         k -= below;
-        const int c = k % side;
-        *sx = c < pr.x0 ? c : c + rw, *sy = pr.y0 + k / side;
+        const uint32_t row = fd_div(k, pd.side), c = k - row * pd.side.d;
+        *sx = c < (uint32_t)pr.x0 ? c : c + (uint32_t)rw, *sy = (uint32_t)pr.y0 + row;
     } else {
         k -= below + mid;
-        *sx = k % sx_n, *sy = pr.y1 + 1 + k / sx_n;
+        const uint32_t row = fd_div(k, sxn);
+        *sx = k - row * sxn.d, *sy = (uint32_t)pr.y1 + 1u + row;
     }
 }
-__device__ __forceinline__ bool block_to_tile(int b, int st, int tiles_x, int tiles_y, PriorityRect pr, int* tx, int* ty,
-                                              const int32_t* order = nullptr, int* super_out = nullptr) {
-    const int x = b & 7, j = b >> 3;
-    const int per = st * st;
-    const int super = (j / per) * 8 + x;
-    const int in = j % per;
-    const int sx_n = (tiles_x + st - 1) / st;
-    int sx, sy;
+__device__ __forceinline__ bool block_to_tile(int b, const TileMap& tm, int tiles_x, int tiles_y, const PriorityRect& pr,
+                                              const PriorityDivs& pd, int* tx, int* ty, const int32_t* order = nullptr,
+                                              int* super_out = nullptr) {
+    const uint32_t x = (uint32_t)b & 7u, j = (uint32_t)b >> 3;
+    const uint32_t js = fd_div(j, tm.per), in = j - js * tm.per.d;
+    const uint32_t super = js * 8u + x;
+    uint32_t sx, sy;
     if (order) {
-        const int idx = order[super];  // (a permutation of the padded super-tile range)
-        sx = idx % sx_n, sy = idx / sx_n;
+        const uint32_t idx = (uint32_t)order[super];  // (a permutation of the padded super-tile range)
+        sy = fd_div(idx, tm.sxn), sx = idx - sy * tm.sxn.d;
     } else {
-        priority_super(super, sx_n, pr, &sx, &sy);
+        priority_super(super, tm.sxn, pr, pd, &sx, &sy);
     }
-    if (super_out) *super_out = sy * sx_n + sx;
-    *tx = sx * st + in % st;
-    *ty = sy * st + in / st;
+    if (super_out) *super_out = (int)(sy * tm.sxn.d + sx);
+    const uint32_t iy = fd_div(in, tm.st), ix = in - iy * tm.st.d;
+    *tx = (int)(sx * tm.st.d + ix);
+    *ty = (int)(sy * tm.st.d + iy);
     return *tx < tiles_x && *ty < tiles_y;
 }
 
@@ -817,8 +863,9 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES) void k_render(const RenderArgs a)
     int tx, ty, block = blockIdx.x;
     float cam[14];
     PriorityRect prio;
-    const int frame = select_frame(a, &block, cam, &prio);
-    const bool in_image = block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, prio, &tx, &ty);
+    PriorityDivs pdiv;
+    const int frame = select_frame(a, &block, cam, &prio, &pdiv);
+    const bool in_image = block_to_tile(block, a.map, a.tiles_x, a.tiles_y, prio, pdiv, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
     const int r = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);  // local row
@@ -922,12 +969,13 @@ __global__ __launch_bounds__(64 * BLOCK_WAVES)
     int tx, ty, block = blockIdx.x;
     float cam[14];
     PriorityRect prio;
-    const int frame = select_frame(a, &block, cam, &prio);
+    PriorityDivs pdiv;
+    const int frame = select_frame(a, &block, cam, &prio, &pdiv);
     int super_idx = 0;
     unsigned long long heat_t0 = 0;
     if (HEAT) heat_t0 = __builtin_amdgcn_s_memrealtime();
-    const bool in_image = HEAT ? block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, prio, &tx, &ty, a.order, &super_idx)
-                               : block_to_tile(block, a.supertile, a.tiles_x, a.tiles_y, prio, &tx, &ty);
+    const bool in_image = HEAT ? block_to_tile(block, a.map, a.tiles_x, a.tiles_y, prio, pdiv, &tx, &ty, a.order, &super_idx)
+                               : block_to_tile(block, a.map, a.tiles_x, a.tiles_y, prio, pdiv, &tx, &ty);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int x = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
     const int r = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);

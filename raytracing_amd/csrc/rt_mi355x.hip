@@ -249,6 +249,7 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st, bool noal
     a.width = r.width, a.height = r.height, a.local_rows = r.local_rows;
     a.band_rows = r.band_rows, a.rank = r.rank, a.world = r.world;
     a.tiles_x = (r.width + 7) / 8, a.tiles_y = (r.local_rows + 7) / 8;
+    a.fd_band = make_fastdiv((uint32_t)r.band_rows), a.fd_tiles_x = make_fastdiv((uint32_t)a.tiles_x);
     a.n_lights = r.scene.lights_len / 6;
     a.iter = 0;
     const size_t n0 = (size_t)a.tiles_x * a.tiles_y * 64;
@@ -933,10 +934,19 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
     const int n_super = ((a.tiles_x + a.supertile - 1) / a.supertile) * ((a.tiles_y + a.supertile - 1) / a.supertile);
     const int n_blocks = ((n_super + 7) / 8) * 8 * a.supertile * a.supertile;
     a.blocks_per_frame = n_blocks;
+    const int sx_n = (a.tiles_x + a.supertile - 1) / a.supertile;
+    a.map.per = make_fastdiv((uint32_t)(a.supertile * a.supertile)), a.map.st = make_fastdiv((uint32_t)a.supertile);
+    a.map.sxn = make_fastdiv((uint32_t)sx_n), a.map.frames = make_fastdiv((uint32_t)n_frames);
+    a.map.band = make_fastdiv((uint32_t)band_rows);
     for (int f = 0; f < MAX_BATCH; f++) a.prio[f] = PriorityRect{1, 1, 0, 0};
     if (ctx->prioritise)
         for (int f = 0; f < n_frames; f++)
             a.prio[f] = priority_rect(a.scene, camera + 14 * f, w, a.local_rows, a.supertile * TILE_X);
+    for (int f = 0; f < MAX_BATCH; f++) {
+        const int rw = a.prio[f].x1 - a.prio[f].x0 + 1;
+        a.prio_div[f].rw = make_fastdiv((uint32_t)std::max(rw, 1));
+        a.prio_div[f].side = make_fastdiv((uint32_t)std::max(sx_n - rw, 1));
+    }
     a.rgb = d_rgb;
     a.rgba8 = (uint32_t*)d_rgba8;
     a.primary_id = d_primary_id;

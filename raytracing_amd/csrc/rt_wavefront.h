@@ -29,6 +29,7 @@ struct WfArgs {
     int max_bounces;
     int width, height, local_rows, band_rows, rank, world;
     int tiles_x, tiles_y;  // 8x8-pixel tiles of the local frame: iteration 0 walks pixels in tile order
+    FastDiv fd_band, fd_tiles_x;  // divisions by band_rows and tiles_x
     int n_lights;
     int iter;
     uint32_t n0;  // work items of iteration 0 = tiles * 64
@@ -51,15 +52,18 @@ __device__ __forceinline__ uint32_t wf_pack_hit(int kind, int index) { return ((
 
 // work item k of iteration 0 -> local pixel index, or -1 outside the image (ragged right/top tiles)
 __device__ __forceinline__ int wf_pixel_of(const WfArgs& a, uint32_t k, int* x_out, int* r_out) {
-    const int tile = (int)(k >> 6), in = (int)(k & 63);
-    const int x = (tile % a.tiles_x) * 8 + (in & 7);
-    const int r = (tile / a.tiles_x) * 8 + (in >> 3);
+    const uint32_t tile = k >> 6;
+    const int in = (int)(k & 63);
+    const uint32_t trow = fd_div(tile, a.fd_tiles_x);
+    const int x = (int)(tile - trow * a.fd_tiles_x.d) * 8 + (in & 7);
+    const int r = (int)trow * 8 + (in >> 3);
     *x_out = x, *r_out = r;
     if (x >= a.width || r >= a.local_rows) return -1;
     return r * a.width + x;
 }
 __device__ __forceinline__ int wf_global_row(const WfArgs& a, int r) {
-    return ((r / a.band_rows) * a.world + a.rank) * a.band_rows + r % a.band_rows;
+    const uint32_t band = fd_div((uint32_t)r, a.fd_band);  // r / band_rows (FastDiv, rt_kernels.h)
+    return (int)((band * (uint32_t)a.world + (uint32_t)a.rank) * (uint32_t)a.band_rows + ((uint32_t)r - band * (uint32_t)a.band_rows));
 }
 // (selected without indexing the by-value argument struct, which would force a copy of it to scratch)
 __device__ __forceinline__ const uint32_t* wf_list_in(const WfArgs& a) { return (a.iter & 1) ? a.list[1] : a.list[0]; }
