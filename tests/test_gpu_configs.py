@@ -113,15 +113,16 @@ def _stress_cameras(g, ext, n, w, h):
     return cams
 
 
-@pytest.mark.parametrize("name,params,depth,ext", [("TeapotTable", None, 8, 12.0), ("Soup", [8000, 80, 8], 4, 60.0)])
+@pytest.mark.parametrize("name,params,depth,ext", [("TeapotTable", None, 8, 12.0), ("Soup", [8000, 80, 8], 4, 60.0),
+                                                   ("TestScene1", None, 10, 12.0), ("Soup", [20000, 200, 8], 4, 60.0)])
 def test_stress_every_traversal_against_the_oracle(name, params, depth, ext, rt, scene_of):
-    """~25 random cameras per scene x 5 kernels, each frame compared with the oracle (not HIP with HIP):
+    """150 random cameras per scene x 5 kernels, each frame compared with the oracle (not HIP with HIP):
     ids bit-exact, colours within tolerance.  Covers the distance cull and the tight tree's pads on views
     the fixed cases do not have (eye inside the mesh, grazing the mirror floor, axis-aligned rays)."""
     sc = scene_of(name, params)
     w, h = 96, 54
     # RT_STRESS_CAMERAS / RT_STRESS_SEED (development): a longer sweep with other cameras, for the record in profiles/
-    n_cams = int(os.environ.get("RT_STRESS_CAMERAS", "25"))
+    n_cams = int(os.environ.get("RT_STRESS_CAMERAS", "150"))
     cams = _stress_cameras(np.random.default_rng(int(os.environ.get("RT_STRESS_SEED", "20250211"))), ext, n_cams, w, h)
     refs = [oracle_render(sc, cam, depth, threads=16) for cam in cams]
     try:
