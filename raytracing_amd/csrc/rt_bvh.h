@@ -111,6 +111,10 @@ struct Bvh {
     std::vector<Node> nodes;
     int levels = 0;  // deepest chain of inner nodes actually built (<= MAX_LEVELS)
     int64_t leaves = 0;
+    // tight tree only: index of a second root holder for rays whose origin lies inside near_lo..near_hi (its second
+    // child is a spheres' tree with pads sized for such origins, build_tight); 0 = none
+    uint32_t near_root = 0;
+    float near_lo[3] = {0, 0, 0}, near_hi[3] = {0, 0, 0};
 };
 
 namespace detail {
@@ -314,28 +318,44 @@ struct Builder {
 }  // namespace detail
 
 namespace detail {
-// Builds items[0, split) and items[split, n) as the two children of the root holder (node 0), so a
+// Builds items[0, split) and items[split, split2) as the two children of the root holder (node 0), so a
 // traversal always starts with `cur = 0`.  split == n: one tree, the second child is an empty leaf.
-inline void build_items(std::vector<Item>& items, size_t split, Bvh* out) {
+// split2 < n (tight tree only): items[split2, n) become a third tree, and a second root holder -- the LAST node,
+// out->near_root -- holds the first tree and that one.
+inline void build_items(std::vector<Item>& items, size_t split, Bvh* out, size_t split2 = (size_t)-1) {
     out->nodes.clear();
     out->levels = 0;
-    out->leaves = (int64_t)items.size();
+    out->near_root = 0;
+    if (split2 > items.size()) split2 = items.size();
+    out->leaves = (int64_t)split2;
     if (items.empty()) return;
-    const size_t n_a = split, n_b = items.size() - split;
-    out->nodes.assign(1 + (n_a ? n_a - 1 : 0) + (n_b ? n_b - 1 : 0), Node{});  // node 0: root holder
+    const size_t bounds[4] = {0, split, split2, items.size()};
+    const bool third = split2 < items.size();
+    size_t base[3], at = 1;  // node 0: root holder
+    for (int h = 0; h < 3; h++) {
+        const size_t n = bounds[h + 1] - bounds[h];
+        base[h] = at, at += n ? n - 1 : 0;  // a subtree over n items owns n - 1 nodes
+    }
+    out->nodes.assign(at + (third ? 1 : 0), Node{});
     Builder bld{items, *out};
     bld.levels = 1;
-    Box box[2];
-    uint32_t ref[2] = {LEAF, LEAF};  // empty leaf (count 0): harmless even if its box were accepted
-    for (int h = 0; h < 2; h++) {
-        const size_t b = h ? split : 0, e = h ? items.size() : split;
+    Box box[3];
+    uint32_t ref[3] = {LEAF, LEAF, LEAF};  // empty leaf (count 0): harmless even if its box were accepted
+    for (int h = 0; h < 3; h++) {
+        const size_t b = bounds[h], e = bounds[h + 1];
         box[h].reset();  // inverted: rejected by any finite ray
-        if (e > b) ref[h] = bld.build(b, e, 1, &box[h], (uint32_t)(h ? 1 + (n_a ? n_a - 1 : 0) : 1), 4);
+        if (e > b) ref[h] = bld.build(b, e, 1, &box[h], (uint32_t)base[h], 4);
     }
     out->levels = bld.levels.load();
     Node& h = out->nodes[0];
     h.set_child(0, box[0].lo, box[0].hi, ref[0]), h.set_child(1, box[1].lo, box[1].hi, ref[1]);
     h.pad[0] = h.pad[1] = 0;
+    if (third) {
+        out->near_root = (uint32_t)at;
+        Node& h2 = out->nodes[at];
+        h2.set_child(0, box[0].lo, box[0].hi, ref[0]), h2.set_child(1, box[2].lo, box[2].hi, ref[2]);
+        h2.pad[0] = h2.pad[1] = 0;
+    }
 }
 }  // namespace detail
 
@@ -435,14 +455,31 @@ struct TightInput {
     const unsigned char* spheres = nullptr;  // SphereStruct records, 48 B: center, radius
     float pad_tri = 0, pad_sphere = 0;
     const std::vector<uint8_t>* tri_unbounded = nullptr;  // per triangle slot: accepted on a line / plane (rtf::meta_nocull)
+    // Origins of many rays of a frame -- shadow and bounce rays from hit points on the primitives -- lie inside the
+    // scene's root box (grown a little: near_lo..near_hi).  For such an origin |o - c| is bounded per sphere by the
+    // distance D from its centre to the farthest corner of that region, so its pad can be NEAR_REL * D (+ pad_tri)
+    // instead of pad_sphere, which is sized for origins up to E_build away (Soup1M: 0.13-0.25 against 0.625 around
+    // spheres of radius 0.05-0.4).  near_on: build that second spheres' tree (Bvh::near_root).
+    bool near_on = false;
+    float near_lo[3] = {0, 0, 0}, near_hi[3] = {0, 0, 0};
 };
+constexpr double NEAR_REL = 2.05e-3;  // the sphere bound of the proof above (X_c within 2.0e-3 |o-c| of the sphere), with room
+// pad of a sphere's box in the tree for near origins
+inline double near_sphere_pad(const float* rec, const TightInput& in) {
+    double d2 = 0;
+    for (int c = 0; c < 3; c++) {
+        const double far = std::max(std::fabs((double)rec[c] - in.near_lo[c]), std::fabs((double)in.near_hi[c] - rec[c]));
+        d2 += far * far;
+    }
+    return NEAR_REL * std::sqrt(d2) + in.pad_tri;
+}
 
 inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, std::vector<int32_t>* tri_slot_leaf,
                         std::vector<int32_t>* sphere_slot_leaf) {
     // triangles and spheres get a tree each (the two children of the root holder): the spheres' pad is
     // 64 x the triangles', mixed in they would inflate every inner box above them
-    std::vector<detail::Item> items, sphere_items;
-    items.reserve(flat.tri_slot_id.size() + flat.sphere_slot_id.size());
+    std::vector<detail::Item> items, sphere_items, near_items;
+    items.reserve(flat.tri_slot_id.size() + 2 * flat.sphere_slot_id.size());
     tri_slot_leaf->assign(flat.tri_slot_id.size(), 0);
     sphere_slot_leaf->assign(flat.sphere_slot_id.size(), 0);
     auto down = [](double x) {
@@ -453,7 +490,8 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
         float f = (float)x;
         return (double)f < x ? std::nextafterf(f, INFINITY) : f;
     };
-    auto fill = [&](size_t n0, size_t n1, std::vector<detail::Item>& items, std::vector<detail::Item>& sphere_items) {
+    auto fill = [&](size_t n0, size_t n1, std::vector<detail::Item>& items, std::vector<detail::Item>& sphere_items,
+                    std::vector<detail::Item>& near_items) {
     for (size_t ni = n0; ni < n1; ni++) {
         const rtf::FlatNode& fn = flat.nodes[ni];
         const int count = (fn.meta >> 24) & 31, first = (int)(fn.meta & 0xFFFFFF);
@@ -475,6 +513,7 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
                 for (int c = 0; c < 3; c++) it.lo[c] = down((double)flo[c] - in.pad_tri), it.hi[c] = up((double)fhi[c] + in.pad_tri);
                 it.ref = LEAF | ((uint32_t)rtf::KIND_TRI_UNBOUNDED << 29) | (1u << 24) | (uint32_t)slot;
                 sphere_items.push_back(it);
+                if (in.near_on) near_items.push_back(it);  // (reachable from either root holder)
                 continue;
             }
             if (kind == rtf::KIND_TRI) {
@@ -499,6 +538,12 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
                 const float* r = (const float*)(in.spheres + (size_t)flat.sphere_slot_id[slot] * 48);
                 for (int c = 0; c < 3; c++) lo[c] = (double)r[c] - r[3], hi[c] = (double)r[c] + r[3];
                 pad = in.pad_sphere;
+                if (in.near_on) {
+                    const double np = std::min(near_sphere_pad(r, in), (double)in.pad_sphere);
+                    detail::Item nit = it;
+                    for (int c = 0; c < 3; c++) nit.lo[c] = down(lo[c] - np), nit.hi[c] = up(hi[c] + np);
+                    near_items.push_back(nit);
+                }
             }
             for (int c = 0; c < 3; c++) it.lo[c] = down(lo[c] - pad), it.hi[c] = up(hi[c] + pad);
             (kind == rtf::KIND_TRI ? items : sphere_items).push_back(it);
@@ -510,21 +555,29 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
     const size_t n_nodes = flat.nodes.size();
     const int n_threads = n_nodes < (1u << 16) ? 1 : (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
     if (n_threads == 1) {
-        fill(0, n_nodes, items, sphere_items);
+        fill(0, n_nodes, items, sphere_items, near_items);
     } else {
-        std::vector<std::vector<detail::Item>> part(n_threads), sphere_part(n_threads);
+        std::vector<std::vector<detail::Item>> part(n_threads), sphere_part(n_threads), near_part(n_threads);
         Crew crew;
         for (int t = 0; t < n_threads; t++)
-            crew.start([&, t] { fill(n_nodes * t / n_threads, n_nodes * (t + 1) / n_threads, part[t], sphere_part[t]); });
+            crew.start([&, t] { fill(n_nodes * t / n_threads, n_nodes * (t + 1) / n_threads, part[t], sphere_part[t], near_part[t]); });
         crew.finish();
         for (int t = 0; t < n_threads; t++) {
             items.insert(items.end(), part[t].begin(), part[t].end());
             sphere_items.insert(sphere_items.end(), sphere_part[t].begin(), sphere_part[t].end());
+            near_items.insert(near_items.end(), near_part[t].begin(), near_part[t].end());
         }
     }
+    // (a near tree that holds no sphere -- only unbounded triangles, or nothing -- would be the far tree again)
+    bool any_sphere = false;
+    for (const detail::Item& it : near_items) any_sphere |= ((it.ref >> 29) & 3) == (uint32_t)rtf::KIND_SPHERE;
+    if (!any_sphere) near_items.clear();
     const size_t split = items.size();
     items.insert(items.end(), sphere_items.begin(), sphere_items.end());
-    detail::build_items(items, split, out);
+    const size_t split2 = items.size();
+    items.insert(items.end(), near_items.begin(), near_items.end());
+    detail::build_items(items, split, out, split2);
+    for (int c = 0; c < 3; c++) out->near_lo[c] = in.near_lo[c], out->near_hi[c] = in.near_hi[c];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -550,6 +603,7 @@ static_assert(sizeof(QNode) == 32, "QNode is two 16-byte loads");
 struct QBvh {
     std::vector<QNode> nodes;
     float base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
+    uint32_t near_root = 0;  // Bvh::near_root
     // the box child `side` of node i stands for (what the traversal tests against)
     void get_box(size_t i, int side, double* lo, double* hi) const {
         for (int c = 0; c < 3; c++) {
@@ -581,6 +635,7 @@ inline bool quantize(const Bvh& in, QBvh* out) {
         out->step[c] = st;
     }
     out->nodes.resize(in.nodes.size());
+    out->near_root = in.near_root;
     const size_t n = in.nodes.size();
     auto run = [&](size_t b, size_t e) {
         for (size_t i = b; i < e; i++) {

@@ -63,7 +63,17 @@ struct DevScene {
     float tight_e;
     const int32_t* tri_slot_leaf;
     const int32_t* sphere_slot_leaf;
+    // second root holder of the tight tree (rtb::Bvh::near_root; 0 = none): rays whose origin lies inside
+    // near_lo..near_hi start there -- the same triangles' tree, and the spheres' tree whose pads are sized for them
+    uint32_t tight_near_root;
+    float near_lo[3], near_hi[3];
 };
+// where a ray that walks the tight tree starts (tight_root(S, o)); 0 = the first root holder
+__device__ __forceinline__ uint32_t tight_root(const DevScene& S, V3 o) {
+    const bool inside = (o.x >= S.near_lo[0]) & (o.x <= S.near_hi[0]) & (o.y >= S.near_lo[1]) & (o.y <= S.near_hi[1]) &
+                        (o.z >= S.near_lo[2]) & (o.z <= S.near_hi[2]);
+    return inside ? S.tight_near_root : 0u;
+}
 
 struct GeomGlobal {
     const float4* base;

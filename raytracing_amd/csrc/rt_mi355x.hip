@@ -565,6 +565,8 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     s.tight = tight_q.nodes.empty() ? nullptr : (const uint4*)((const float4*)ctx->geom.p + geom_f4);
     for (int k = 0; k < 3; k++) s.tight_base[k] = tight_q.base[k], s.tight_step[k] = tight_q.step[k];
     s.tight_e = tight_e;
+    s.tight_near_root = tight_q.nodes.empty() ? 0u : tight_q.near_root;
+    for (int k = 0; k < 3; k++) s.near_lo[k] = tight.near_lo[k], s.near_hi[k] = tight.near_hi[k];
     s.tri_slot_leaf = (const int32_t*)ctx->tri_slot_leaf.p;
     s.sphere_slot_leaf = (const int32_t*)ctx->sphere_slot_leaf.p;
 

@@ -178,6 +178,15 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
             in.tris = triangles, in.spheres = spheres;
             in.pad_tri = out->pad_tri, in.pad_sphere = out->pad_sphere;
             in.tri_unbounded = &out->tri_unbounded;
+            // origins inside the root box grown by max_extent / 32 (hit points lie within the cull's pad, <= max_extent / 64
+            // there, of a primitive) walk the spheres' tree with the per-sphere pads (rt_bvh.h TightInput)
+            in.near_on = !flat.nodes.empty();
+            if (in.near_on) {
+                const rtf::FlatNode& root = flat.nodes[0];
+                const float rlo[3] = {root.minx, root.miny, root.minz}, rhi[3] = {root.maxx, root.maxy, root.maxz};
+                const float grow = 1.0f / 32.0f;  // (measured on Soup1M 4K: 1/32 48.0 ms, 1/2 47.8, 1 48.5, 2 50.2)
+                for (int k = 0; k < 3; k++) in.near_lo[k] = rlo[k] - max_extent * grow, in.near_hi[k] = rhi[k] + max_extent * grow;
+            }
             rtb::build_tight(flat, in, &out->tight, &out->tri_slot_leaf, &out->sphere_slot_leaf);
         });
     if (flat.nested) rtb::build(flat, &out->bvh);
@@ -204,6 +213,16 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
 inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, const unsigned char* spheres,
                                const unsigned char* triangles) {
     if (t.nodes.empty()) return "";
+    std::vector<uint8_t> visited_node(t.nodes.size(), 0);
+    // the tight tree may have a second root holder (rtb::Bvh::near_root: the triangles' tree again + the spheres' tree
+    // for near origins): every slot must be reached exactly once from EITHER holder, with that holder's pads
+    for (int pass = 0; pass < (t.near_root ? 2 : 1); pass++) {
+    const bool near = pass == 1;
+    rtb::TightInput near_in;
+    if (tight_of) {
+        near_in.pad_tri = tight_of->pad_tri, near_in.pad_sphere = tight_of->pad_sphere;
+        for (int k = 0; k < 3; k++) near_in.near_lo[k] = t.near_lo[k], near_in.near_hi[k] = t.near_hi[k];
+    }
     std::vector<uint8_t> seen_tri, seen_sph;
     if (tight_of) seen_tri.assign(tight_of->flat.tri_slot_id.size(), 0), seen_sph.assign(tight_of->flat.sphere_slot_id.size(), 0);
     struct Todo {
@@ -225,8 +244,10 @@ inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, cons
             push(nd.ref[c], lo, hi, level);
         }
     };
-    push_children(t.nodes[0], 1);
-    size_t visited = 1;
+    const uint32_t holder = near ? t.near_root : 0u;
+    if (holder >= t.nodes.size()) return "second root holder out of range";
+    push_children(t.nodes[holder], 1);
+    visited_node[holder] = 1;
     while (!stack.empty()) {
         const Todo td = stack.back();
         stack.pop_back();
@@ -237,9 +258,22 @@ inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, cons
             if (kind == rtf::KIND_SPHERE) {
                 if (seen_sph[first]++) return "sphere slot reached twice";
                 const float* rec = (const float*)(spheres + (size_t)tight_of->flat.sphere_slot_id[first] * 48);
+                const double sphere_pad = near ? std::min(rtb::near_sphere_pad(rec, near_in), (double)tight_of->pad_sphere) : (double)tight_of->pad_sphere;
+                if (near) {  // the pad covers 2.0e-3 |o - c| for every origin of the near region (checked at its corners)
+                    double worst = 0;
+                    for (int corner = 0; corner < 8; corner++) {
+                        double d2 = 0;
+                        for (int c = 0; c < 3; c++) {
+                            const double x = (corner >> c) & 1 ? t.near_hi[c] : t.near_lo[c];
+                            d2 += (x - rec[c]) * (x - rec[c]);
+                        }
+                        worst = std::max(worst, std::sqrt(d2));
+                    }
+                    if (!(sphere_pad >= std::min(2.0e-3 * worst, (double)tight_of->pad_sphere))) return "near pad of a sphere below its error bound";
+                }
                 for (int c = 0; c < 3; c++)
-                    if (!((double)rec[c] - rec[3] - tight_of->pad_sphere >= td.lo[c] - 1e-6 * std::fabs(td.lo[c]) &&
-                          (double)rec[c] + rec[3] + tight_of->pad_sphere <= td.hi[c] + 1e-6 * std::fabs(td.hi[c])))
+                    if (!((double)rec[c] - rec[3] - sphere_pad >= td.lo[c] - 1e-6 * std::fabs(td.lo[c]) &&
+                          (double)rec[c] + rec[3] + sphere_pad <= td.hi[c] + 1e-6 * std::fabs(td.hi[c])))
                         return "sphere sticks out of its padded tight box";
             } else {
                 if (seen_tri[first]++) return "triangle slot reached twice";
@@ -271,9 +305,10 @@ inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, cons
             continue;
         }
         const uint32_t idx = td.ref & rtb::INDEX_MASK;
-        if (idx == 0 || idx >= t.nodes.size()) return "inner ref out of range";
+        if (idx == 0 || idx >= t.nodes.size() || (t.near_root && idx == t.near_root)) return "inner ref out of range";
         if (td.level + 1 > rtb::MAX_LEVELS || td.level + 1 > t.levels) return "deeper than the recorded level count";
-        visited++;
+        if (visited_node[idx] > (near ? 1 : 0)) return "shared nodes";
+        visited_node[idx] = near ? 2 : 1;
         const rtb::Node& nd = t.nodes[idx];
         for (int k = 0; k < 3; k++)
             if (std::fmin(nd.lo[k][0], nd.lo[k][1]) != td.lo[k] || std::fmax(nd.hi[k][0], nd.hi[k][1]) != td.hi[k])
@@ -281,13 +316,15 @@ inline std::string verify_tree(const rtb::Bvh& t, const Prepared* tight_of, cons
         if (rtb::ref_nocull(td.ref) != (rtb::ref_nocull(nd.ref[0]) || rtb::ref_nocull(nd.ref[1]))) return "never-cull mark not propagated";
         push_children(nd, td.level + 1);
     }
-    if (visited != t.nodes.size()) return "unreachable or shared nodes";
     if (tight_of) {
         for (uint8_t s : seen_tri)
             if (s != 1) return "triangle slot missing from the tight tree";
         for (uint8_t s : seen_sph)
             if (s != 1) return "sphere slot missing from the tight tree";
     }
+    }  // pass
+    for (uint8_t v : visited_node)
+        if (!v) return "unreachable nodes";
     return "";
 }
 

@@ -166,7 +166,7 @@ __device__ __forceinline__ void wf_run(const G& g, uint32_t* head, uint32_t tota
 #else
             const uint32_t k = wf_draw(head, total, cur == NONE, &exhausted);
 #endif
-            if (k != NONE && job.setup(k)) cur = 0u, sp = 0, lk = 0;  // the root holder of either tree
+            if (k != NONE && job.setup(k)) cur = job.root, sp = 0, lk = 0;  // a root holder (of the leaf tree: node 0)
             continue;
         }
         if (n_idle == 64) {
@@ -262,6 +262,7 @@ struct WfClosestJob {
     BoxRay br;
     Closest h;
     bool tight;  // this ray walks the tight tree: hits count only if their reference leaf box passes
+    uint32_t root;  // node the walk starts at (tight_root)
     __device__ __forceinline__ float t_hi() const { return h.t; }
     __device__ __forceinline__ bool done() const { return false; }
     __device__ __forceinline__ bool leaf_passes(const int32_t* slot_leaf, int slot) const {
@@ -310,9 +311,10 @@ struct WfClosestJob {
             const float t = IntersectPlane(o, d, v3(pp.x, pp.y, pp.z), v3(nn.x, nn.y, nn.z));
             if (closer(t, 1, q, t_lo, h)) h.t = t, h.kind = 1, h.index = q;
         }
-        tight = false;
+        tight = false, root = 0u;
         if (ray_is_regular(br) && S.n_nodes > 0) {
             tight = S.tight != nullptr && make_tight_ray(br, v3(S.extent[0], S.extent[1], S.extent[2]), S.tight_e, S.tight_base, S.tight_step);
+            if (tight) root = tight_root(S, o);
             return true;
         }
         // zero direction component etc.: the exact tree, exhaustively (rare)
@@ -363,6 +365,7 @@ struct WfAnyJob {
     BoxRay br;
     bool blocked;
     bool tight;  // as in WfClosestJob
+    uint32_t root;
     __device__ __forceinline__ float t_hi() const { return dist; }
     __device__ __forceinline__ bool done() const { return blocked; }
     __device__ __forceinline__ bool in_range(float t) const { return t > RT_EPSILON && t < dist; }
@@ -428,9 +431,10 @@ struct WfAnyJob {
             const float4 pp = S.plane_geom[2 * q], nn = S.plane_geom[2 * q + 1];
             if (in_range(IntersectPlane(o, d, v3(pp.x, pp.y, pp.z), v3(nn.x, nn.y, nn.z)))) blocked = true;
         }
-        tight = false;
+        tight = false, root = 0u;
         if (!blocked && ray_is_regular(br) && S.n_nodes > 0) {
             tight = S.tight != nullptr && make_tight_ray(br, v3(S.extent[0], S.extent[1], S.extent[2]), S.tight_e, S.tight_base, S.tight_step);
+            if (tight) root = tight_root(S, o);
             return true;
         }
         if (!blocked)

@@ -19,7 +19,10 @@ def test_reference_scenes_pass_every_precondition(name, params, scene_of):
     # under the second; a binary tree over m leaves has m - 1 inner nodes
     a = info["n_tri_slots"] - info["unbounded_triangles"]
     b = info["n_sphere_slots"] + info["unbounded_triangles"]
-    assert info["tight_nodes"] == 1 + max(a - 1, 0) + max(b - 1, 0)
+    # ... and, in scenes with spheres, a second root holder (the last node) over the triangles' tree and a second
+    # spheres' tree whose pads are sized for origins inside the scene (rt_bvh.h TightInput::near_on)
+    near = (max(b - 1, 0) + 1) if info["n_sphere_slots"] else 0
+    assert info["tight_nodes"] == 1 + max(a - 1, 0) + max(b - 1, 0) + near
     assert 0 < info["tight_levels"] <= 32 and 0 < info["bvh_levels"] <= 32
     assert info["unbounded_triangles"] == (21 if name == "TeapotTable" else 0)   # 19 collinear + 2 long slivers
     small = check_scene(sc)                             # default threshold (RT_OPTION_TIGHT_MIN_NODES): only large scenes
