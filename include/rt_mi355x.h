@@ -122,6 +122,12 @@ enum {
                                 above.  Scenes with bounces gain 5-20 % (TestScene1, TeapotTable), the teapot frame
                                 loses 8-30 % (lock-step, light rays formed again per queue entry).  Results do not
                                 depend on it */,
+    RT_OPTION_FRAME_FEEDBACK = 9, /* 1 (default): single frames of a scene whose root box spans the view and whose paths may
+                                bounce three times or more deal their tiles out in an order ranked from the PREVIOUS launch's
+                                wave lifetimes (longest first; same scene, size and bounce count), so the second and later
+                                frames of a view are faster than its first (TestScene1 720p depth 10: 0.31 against 0.40 ms).
+                                0: every frame is dealt out in the fixed order -- what a caller sets who wants timings that
+                                do not depend on the frame before.  Pixels never depend on it */
     RT_OPTION_GPU_FLATTEN_MIN = 8 /* accel arrays of at least this many floats (default 65536) are validated and
                                 flattened on the GPU, level by level (bit-identical to the host's walk, which smaller
                                 arrays take and which still words every refusal); -1: never */

@@ -316,6 +316,8 @@ static int multi_upload(rt_ctx* root, const rtp::Prepared& prep, const void* sph
                         int n_planes, const void* triangles, int n_triangles, const float* lights, int lights_len);
 static int multi_render(rt_ctx* root, const float* camera, int max_bounces, float* rgb, uint8_t* rgba8, int32_t* primary_id,
                         int32_t* final_id, rt_stats* stats);
+static int multi_render_device(rt_ctx* root, const float* camera, int max_bounces, float* d_rgb, uint8_t* d_rgba8,
+                               int32_t* d_primary_id, int32_t* d_final_id, void* stream);
 static void multi_release(rt_ctx* root);
 
 extern "C" {
@@ -438,6 +440,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
         case RT_OPTION_COOP_SHADOWS:
             if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "cooperative shadow rays: 0 never, 1 always, 2 measured");
             ctx->coop_shadows = value;
+            return RT_OK;
+        case RT_OPTION_FRAME_FEEDBACK:
+            ctx->use_heat = value != 0;
+            ctx->heat_valid = false;
             return RT_OK;
         case RT_OPTION_GPU_FLATTEN_MIN:
             if (value < -1) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "GPU flatten threshold must be >= -1");
@@ -1044,9 +1050,24 @@ static int render_frames(rt_ctx* ctx, const float* camera, int n_frames, uint64_
     return RT_OK;
 }
 
+static int render_device_one(rt_ctx* ctx, const float camera[14], int max_bounces, int flags, int band_rows, int rank,
+                             int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id, int32_t* d_final_id,
+                             int32_t* d_bounces, rt_stats* d_stats, void* stream);
 int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int flags, int band_rows, int rank,
                      int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id, int32_t* d_final_id,
                      int32_t* d_bounces, rt_stats* d_stats, void* stream) {
+    // a multi-GPU context asked for a WHOLE frame (rank 0 of world 1, no bounce plane, no counters): every device renders
+    // its bands, the planes are assembled in the caller's buffers on the root device (rt_multi.h).  The per-device
+    // contexts inside it are plain contexts (multi == nullptr) and take the path below.
+    if (ctx && ctx->multi && rank == 0 && world == 1 && !(flags & RT_RENDER_REFERENCE_ORDER) && !d_bounces && !d_stats)
+        return multi_render_device(ctx, camera, max_bounces, d_rgb, d_rgba8, d_primary_id, d_final_id, stream);
+    return render_device_one(ctx, camera, max_bounces, flags, band_rows, rank, world, d_rgb, d_rgba8, d_primary_id, d_final_id,
+                             d_bounces, d_stats, stream);
+}
+// rt_render_device on ONE device (also what a multi-GPU context runs on each of its devices, the root included)
+static int render_device_one(rt_ctx* ctx, const float camera[14], int max_bounces, int flags, int band_rows, int rank,
+                             int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id, int32_t* d_final_id,
+                             int32_t* d_bounces, rt_stats* d_stats, void* stream) {
     int timed = -1, force = 0, w, h;
     if (ctx && ctx->has_scene && !(flags & RT_RENDER_REFERENCE_ORDER) && camera_size(camera, &w, &h) == RT_OK &&
         band_rows > 0 && world > 0 && rank >= 0 && rank < world && hipSetDevice(ctx->device) == hipSuccess)

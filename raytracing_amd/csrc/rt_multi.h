@@ -87,6 +87,7 @@ struct rt_multi {
     std::vector<Planes> local;  // each device's own bands: rt_padded_rows() x W pixels per plane
     DevBuf gathered;            // root: [n][padded rows][W] elements of the plane being assembled
     std::vector<hipEvent_t> done;  // copy path: device d's render has finished
+    hipEvent_t enter = nullptr, leave = nullptr;  // root device: rt_render_device on this context joins the caller's stream
 };
 
 namespace {
@@ -119,6 +120,8 @@ static void multi_release(rt_ctx* root) {
         if (d < (int)m->stream.size() && m->stream[d]) (void)hipStreamDestroy(m->stream[d]);
     }
     (void)hipSetDevice(root->device);
+    if (m->enter) (void)hipEventDestroy(m->enter);
+    if (m->leave) (void)hipEventDestroy(m->leave);
     release(m->gathered);
     for (int d = 1; d < (int)m->sub.size(); d++)
         if (m->sub[d]) rt_destroy(m->sub[d]);
@@ -142,36 +145,140 @@ static int multi_upload(rt_ctx* root, const rtp::Prepared& prep, const void* sph
     return RT_OK;
 }
 
-// One plane's bands from every device to the root, then scanline order into `out` (a root device buffer).
-static int multi_gather_plane(rt_ctx* root, size_t elem, int w, int h, const std::vector<void*>& src, void* out) {
+// The requested planes' bands from every device to the root in ONE exchange, then scanline order into the root
+// device buffers out[k].  RCCL: a single group holds every (plane, device) send/receive pair -- each device sends its
+// chunk of each plane to rank 0, rank 0 receives n chunks per plane (its own included: a send to self inside a group is
+// a local copy), all progressing concurrently on their own links.
+struct MultiPlane {
+    size_t elem;                       // bytes per pixel
+    DevBuf rt_multi::Planes::*plane;   // where every device rendered it
+    void* out;                         // root device buffer, H x W pixels
+};
+static int multi_gather_planes(rt_ctx* root, const MultiPlane* planes, int n_planes, int w, int h) {
     rt_multi* m = root->multi;
     const int padded = rt_padded_rows(h, MULTI_BAND_ROWS, m->n);
-    const size_t chunk = (size_t)padded * w * elem;
+    size_t total = 0;
+    for (int k = 0; k < n_planes; k++) total += (size_t)padded * w * planes[k].elem * m->n;
     HIP_TRY(root, hipSetDevice(root->device));
-    int rc = ensure(root, m->gathered, chunk * m->n);
+    int rc = ensure(root, m->gathered, total);
     if (rc != RT_OK) return rc;
     unsigned char* g = (unsigned char*)m->gathered.p;
     if (m->use_rccl) {
-        // grouped: every device sends its chunk to rank 0, rank 0 receives n chunks (its own included: a
-        // send to self inside a group is a local copy), all progressing concurrently on their own links
         NCCL_TRY(root, g_rccl.GroupStart());
         ncclResult_t bad = ncclSuccess;
         const char* what = "";
-        for (int d = 0; d < m->n && bad == ncclSuccess; d++) {
-            if ((bad = g_rccl.Send(src[d], chunk, ncclUint8, 0, m->comm[d], m->stream[d])) != ncclSuccess) what = "ncclSend";
-            else if ((bad = g_rccl.Recv(g + chunk * d, chunk, ncclUint8, d, m->comm[0], m->stream[0])) != ncclSuccess) what = "ncclRecv";
+        size_t at = 0;
+        for (int k = 0; k < n_planes && bad == ncclSuccess; k++) {
+            const size_t chunk = (size_t)padded * w * planes[k].elem;
+            for (int d = 0; d < m->n && bad == ncclSuccess; d++) {
+                const void* src = (m->local[d].*(planes[k].plane)).p;
+                if ((bad = g_rccl.Send(src, chunk, ncclUint8, 0, m->comm[d], m->stream[d])) != ncclSuccess) what = "ncclSend";
+                else if ((bad = g_rccl.Recv(g + at + chunk * d, chunk, ncclUint8, d, m->comm[0], m->stream[0])) != ncclSuccess) what = "ncclRecv";
+            }
+            at += chunk * m->n;
         }
         // a group that was opened is always closed, whatever happened inside it
         const ncclResult_t end = g_rccl.GroupEnd();
         if (bad != ncclSuccess) return nccl_fail(root, bad, what);
         if (end != ncclSuccess) return nccl_fail(root, end, "ncclGroupEnd");
     } else {
-        for (int d = 0; d < m->n; d++) {
-            HIP_TRY(root, hipStreamWaitEvent(m->stream[0], m->done[d], 0));
-            HIP_TRY(root, hipMemcpyAsync(g + chunk * d, src[d], chunk, hipMemcpyDeviceToDevice, m->stream[0]));
+        for (int d = 0; d < m->n; d++) HIP_TRY(root, hipStreamWaitEvent(m->stream[0], m->done[d], 0));
+        size_t at = 0;
+        for (int k = 0; k < n_planes; k++) {
+            const size_t chunk = (size_t)padded * w * planes[k].elem;
+            for (int d = 0; d < m->n; d++)
+                HIP_TRY(root, hipMemcpyAsync(g + at + chunk * d, (m->local[d].*(planes[k].plane)).p, chunk, hipMemcpyDeviceToDevice, m->stream[0]));
+            at += chunk * m->n;
         }
     }
-    return rt_unpermute_bands(root, g, out, (int)elem, w, h, MULTI_BAND_ROWS, m->n, m->stream[0]);
+    size_t at = 0;
+    for (int k = 0; k < n_planes; k++) {
+        rc = rt_unpermute_bands(root, g + at, planes[k].out, (int)planes[k].elem, w, h, MULTI_BAND_ROWS, m->n, m->stream[0]);
+        if (rc != RT_OK) return rc;
+        at += (size_t)padded * w * planes[k].elem * m->n;
+    }
+    return RT_OK;
+}
+
+// Every device renders its bands into its own compact planes, on its own stream (after `after`, if given: an event
+// on the ROOT device that the caller's stream has recorded).
+static int multi_launch_bands(rt_ctx* root, const float* camera, int max_bounces, int w, int h, bool rgb, bool rgba8, bool pid,
+                              bool fid, bool stats, hipEvent_t after) {
+    rt_multi* m = root->multi;
+    const int padded = rt_padded_rows(h, MULTI_BAND_ROWS, m->n);
+    const size_t lpx = (size_t)padded * w;
+    int rc;
+    for (int d = 0; d < m->n; d++) {
+        rt_ctx* c = m->sub[d];
+        rt_multi::Planes& L = m->local[d];
+        HIP_TRY(root, hipSetDevice(c->device));
+        if ((rgb && (rc = ensure(c, L.rgb, lpx * 12))) || (rgba8 && (rc = ensure(c, L.rgba8, lpx * 4))) ||
+            (pid && (rc = ensure(c, L.pid, lpx * 4))) || (fid && (rc = ensure(c, L.fid, lpx * 4))) ||
+            (stats && (rc = ensure(c, L.stats, sizeof(rt_stats))))) {
+            root->error = c->error;
+            return rc;
+        }
+        if (after) HIP_TRY(root, hipStreamWaitEvent(m->stream[d], after, 0));
+        if (stats) HIP_TRY(root, hipMemsetAsync(L.stats.p, 0, sizeof(rt_stats), m->stream[d]));
+        c->traversal = root->traversal, c->supertile = root->supertile, c->allow_lds = false, c->coop_shadows = root->coop_shadows;
+        c->use_heat = root->use_heat;
+        rc = render_device_one(c, camera, max_bounces, stats ? RT_RENDER_REFERENCE_ORDER : RT_RENDER_DEFAULT, MULTI_BAND_ROWS, d,
+                              m->n, rgb ? (float*)L.rgb.p : nullptr, rgba8 ? (uint8_t*)L.rgba8.p : nullptr,
+                              pid ? (int32_t*)L.pid.p : nullptr, fid ? (int32_t*)L.fid.p : nullptr, nullptr,
+                              stats ? (rt_stats*)L.stats.p : nullptr, m->stream[d]);
+        if (rc != RT_OK) {
+            if (c != root) root->error = "device " + std::to_string(c->device) + ": " + c->error;
+            return rc;
+        }
+        if (!m->use_rccl) HIP_TRY(root, hipEventRecord(m->done[d], m->stream[d]));
+    }
+    HIP_TRY(root, hipSetDevice(root->device));
+    return RT_OK;
+}
+
+static void multi_drain(rt_ctx* root) {
+    rt_multi* m = root->multi;
+    const std::string first = root->error;  // keep the first failure's message
+    for (int d = 0; d < m->n; d++)
+        if (m->sub[d] && m->stream[d] && hipSetDevice(m->sub[d]->device) == hipSuccess) (void)hipStreamSynchronize(m->stream[d]);
+    (void)hipGetLastError();
+    (void)hipSetDevice(root->device);
+    root->error = first;
+}
+
+// rt_render_device on a multi-GPU context (whole frame: rank 0 of world 1): the finished planes land in the caller's
+// buffers on the ROOT device, and the call is asynchronous on `stream` (a stream of the root device): the devices'
+// own streams start after what `stream` holds so far, and `stream` continues after the assembled planes are in place.
+static int multi_render_device_impl(rt_ctx* root, const float* camera, int max_bounces, float* d_rgb, uint8_t* d_rgba8,
+                                    int32_t* d_primary_id, int32_t* d_final_id, hipStream_t stream) {
+    rt_multi* m = root->multi;
+    int w, h;
+    if (camera_size(camera, &w, &h) != RT_OK)
+        return fail(root, RT_ERR_INVALID_ARGUMENT, "camera[12..13] must hold an integral width/height in 1..65536");
+    if (!root->has_scene) return fail(root, RT_ERR_NO_SCENE, "rt_upload_scene has not succeeded on this context");
+    HIP_TRY(root, hipSetDevice(root->device));
+    HIP_TRY(root, hipEventRecord(m->enter, stream));
+    int rc = multi_launch_bands(root, camera, max_bounces, w, h, d_rgb != nullptr, d_rgba8 != nullptr, d_primary_id != nullptr,
+                                d_final_id != nullptr, false, m->enter);
+    if (rc != RT_OK) return rc;
+    MultiPlane planes[4];
+    int n = 0;
+    if (d_rgb) planes[n++] = MultiPlane{12, &rt_multi::Planes::rgb, d_rgb};
+    if (d_rgba8) planes[n++] = MultiPlane{4, &rt_multi::Planes::rgba8, d_rgba8};
+    if (d_primary_id) planes[n++] = MultiPlane{4, &rt_multi::Planes::pid, d_primary_id};
+    if (d_final_id) planes[n++] = MultiPlane{4, &rt_multi::Planes::fid, d_final_id};
+    if (n && (rc = multi_gather_planes(root, planes, n, w, h)) != RT_OK) return rc;
+    HIP_TRY(root, hipSetDevice(root->device));
+    HIP_TRY(root, hipEventRecord(m->leave, m->stream[0]));
+    HIP_TRY(root, hipStreamWaitEvent(stream, m->leave, 0));
+    // (the other devices' streams have nothing after their sends; the root stream's receive + assembly is what `stream` waits for)
+    return RT_OK;
+}
+static int multi_render_device(rt_ctx* root, const float* camera, int max_bounces, float* d_rgb, uint8_t* d_rgba8,
+                               int32_t* d_primary_id, int32_t* d_final_id, void* stream) {
+    const int rc = multi_render_device_impl(root, camera, max_bounces, d_rgb, d_rgba8, d_primary_id, d_final_id, (hipStream_t)stream);
+    if (rc != RT_OK) multi_drain(root);
+    return rc;
 }
 
 static int multi_render_impl(rt_ctx* root, const float* camera, int max_bounces, float* rgb, uint8_t* rgba8, int32_t* primary_id,
@@ -181,15 +288,7 @@ static int multi_render_impl(rt_ctx* root, const float* camera, int max_bounces,
 static int multi_render(rt_ctx* root, const float* camera, int max_bounces, float* rgb, uint8_t* rgba8, int32_t* primary_id,
                         int32_t* final_id, rt_stats* stats) {
     const int rc = multi_render_impl(root, camera, max_bounces, rgb, rgba8, primary_id, final_id, stats);
-    if (rc != RT_OK) {
-        rt_multi* m = root->multi;
-        const std::string first = root->error;  // keep the first failure's message
-        for (int d = 0; d < m->n; d++)
-            if (m->sub[d] && m->stream[d] && hipSetDevice(m->sub[d]->device) == hipSuccess) (void)hipStreamSynchronize(m->stream[d]);
-        (void)hipGetLastError();
-        (void)hipSetDevice(root->device);
-        root->error = first;
-    }
+    if (rc != RT_OK) multi_drain(root);
     return rc;
 }
 static int multi_render_impl(rt_ctx* root, const float* camera, int max_bounces, float* rgb, uint8_t* rgba8, int32_t* primary_id,
@@ -199,37 +298,16 @@ static int multi_render_impl(rt_ctx* root, const float* camera, int max_bounces,
     if (camera_size(camera, &w, &h) != RT_OK)
         return fail(root, RT_ERR_INVALID_ARGUMENT, "camera[12..13] must hold an integral width/height in 1..65536");
     if (!root->has_scene) return fail(root, RT_ERR_NO_SCENE, "rt_upload_scene has not succeeded on this context");
-    const int padded = rt_padded_rows(h, MULTI_BAND_ROWS, m->n);
-    const size_t lpx = (size_t)padded * w, px = (size_t)w * h;
+    const size_t px = (size_t)w * h;
     int rc;
-    // every device renders its bands into its own compact planes, on its own stream
-    for (int d = 0; d < m->n; d++) {
-        rt_ctx* c = m->sub[d];
-        rt_multi::Planes& L = m->local[d];
-        HIP_TRY(root, hipSetDevice(c->device));
-        if ((rgb && (rc = ensure(c, L.rgb, lpx * 12))) || (rgba8 && (rc = ensure(c, L.rgba8, lpx * 4))) ||
-            (primary_id && (rc = ensure(c, L.pid, lpx * 4))) || (final_id && (rc = ensure(c, L.fid, lpx * 4))) ||
-            (stats && (rc = ensure(c, L.stats, sizeof(rt_stats))))) {
-            root->error = c->error;
-            return rc;
-        }
-        if (stats) HIP_TRY(root, hipMemsetAsync(L.stats.p, 0, sizeof(rt_stats), m->stream[d]));
-        c->traversal = root->traversal, c->supertile = root->supertile, c->allow_lds = false, c->coop_shadows = root->coop_shadows;
-        rc = rt_render_device(c, camera, max_bounces, stats ? RT_RENDER_REFERENCE_ORDER : RT_RENDER_DEFAULT, MULTI_BAND_ROWS, d,
-                              m->n, rgb ? (float*)L.rgb.p : nullptr, rgba8 ? (uint8_t*)L.rgba8.p : nullptr,
-                              primary_id ? (int32_t*)L.pid.p : nullptr, final_id ? (int32_t*)L.fid.p : nullptr, nullptr,
-                              stats ? (rt_stats*)L.stats.p : nullptr, m->stream[d]);
-        if (rc != RT_OK) {
-            if (c != root) root->error = "device " + std::to_string(c->device) + ": " + c->error;
-            return rc;
-        }
-        if (!m->use_rccl) HIP_TRY(root, hipEventRecord(m->done[d], m->stream[d]));
-    }
-    // gather + assemble each requested plane on the root, then hand it to the host
     HIP_TRY(root, hipSetDevice(root->device));
     if ((rgb && (rc = ensure(root, root->fb_rgb, px * 12))) || (rgba8 && (rc = ensure(root, root->fb_rgba8, px * 4))) ||
         (primary_id && (rc = ensure(root, root->fb_pid, px * 4))) || (final_id && (rc = ensure(root, root->fb_fid, px * 4))))
         return rc;
+    if ((rc = multi_launch_bands(root, camera, max_bounces, w, h, rgb != nullptr, rgba8 != nullptr, primary_id != nullptr,
+                                 final_id != nullptr, stats != nullptr, nullptr)) != RT_OK)
+        return rc;
+    // gather + assemble the requested planes on the root (one exchange), then hand them to the host
     struct Job {
         bool want;
         size_t elem;
@@ -240,14 +318,14 @@ static int multi_render_impl(rt_ctx* root, const float* camera, int max_bounces,
                 {rgba8 != nullptr, 4, &rt_multi::Planes::rgba8, &root->fb_rgba8, rgba8},
                 {primary_id != nullptr, 4, &rt_multi::Planes::pid, &root->fb_pid, primary_id},
                 {final_id != nullptr, 4, &rt_multi::Planes::fid, &root->fb_fid, final_id}};
-    for (const Job& j : jobs) {
-        if (!j.want) continue;
-        std::vector<void*> src(m->n);
-        for (int d = 0; d < m->n; d++) src[d] = (m->local[d].*(j.plane)).p;
-        if ((rc = multi_gather_plane(root, j.elem, w, h, src, j.fb->p)) != RT_OK) return rc;
-        HIP_TRY(root, hipSetDevice(root->device));
-        HIP_TRY(root, hipMemcpyAsync(j.host, j.fb->p, px * j.elem, hipMemcpyDeviceToHost, m->stream[0]));
-    }
+    MultiPlane planes[4];
+    int n = 0;
+    for (const Job& j : jobs)
+        if (j.want) planes[n++] = MultiPlane{j.elem, j.plane, j.fb->p};
+    if (n && (rc = multi_gather_planes(root, planes, n, w, h)) != RT_OK) return rc;
+    HIP_TRY(root, hipSetDevice(root->device));
+    for (const Job& j : jobs)
+        if (j.want) HIP_TRY(root, hipMemcpyAsync(j.host, j.fb->p, px * j.elem, hipMemcpyDeviceToHost, m->stream[0]));
     if (stats) {  // every device counted its own bands: the frame's counters are their sum
         std::memset(stats, 0, sizeof *stats);
         for (int d = 0; d < m->n; d++) {
@@ -293,6 +371,10 @@ extern "C" int rt_create_multi(const int* device_ids, int n_devices, rt_ctx** ou
             hipEventCreateWithFlags(&m->done[d], hipEventDisableTiming) != hipSuccess)
             rc = RT_ERR_DEVICE;
     }
+    if (rc == RT_OK && (hipSetDevice(root->device) != hipSuccess ||
+                        hipEventCreateWithFlags(&m->enter, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&m->leave, hipEventDisableTiming) != hipSuccess))
+        rc = RT_ERR_DEVICE;
     if (rc == RT_OK && m->use_rccl) {
         if (!g_rccl.load()) {
             rc = RT_ERR_DEVICE;

@@ -74,3 +74,38 @@ def test_rccl_that_cannot_be_loaded_is_an_error_code_not_a_crash():
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "survived" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
     assert "cannot load librccl.so" in p.stderr
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]], ids=["n1-rccl", "n3-on-one-gpu"])
+def test_multi_context_device_resident_frame(devices, rt, scene_of):
+    """rt_render_device on a multi-GPU context (whole frame): every device renders its bands, ALL requested planes
+    travel in one exchange, and the assembled planes land in the caller's buffers on the root device, asynchronously
+    on the caller's stream -- what `bench.py --capi-multi` times.  Equal to the single-GPU context bit for bit,
+    twice in a row and after a change of size."""
+    import torch
+    sc = scene_of("TeapotTable")
+    rt.SendPrimitivesToShader(sc)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with RayTracer(devices) as m:
+        m.SendPrimitivesToShader(sc)
+        for (w, h) in [(333, 190), (160, 90), (333, 190)]:
+            cam = sc.camera_for(w, h)
+            rt.PrepareRenderOpenGL(cam)
+            single = rt.RenderGL(8)
+            out = {"rgb": torch.full((h, w, 3), -7.0, dtype=torch.float32, device=dev),
+                   "rgba8": torch.zeros((h, w, 4), dtype=torch.uint8, device=dev),
+                   "primary_id": torch.full((h, w), -9, dtype=torch.int32, device=dev),
+                   "final_id": torch.full((h, w), -9, dtype=torch.int32, device=dev)}
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                m.render_device(cam, 8, stream=stream.cuda_stream, **{k: v.data_ptr() for k, v in out.items()})
+                got = {k: v.clone() for k, v in out.items()}   # queued on the same stream: must see the finished planes
+            stream.synchronize()
+            for k in out:
+                assert np.array_equal(got[k].cpu().numpy().view(np.uint8), single[k].view(np.uint8)), (devices, w, h, k)
+            # one plane only
+            only = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+            m.render_device(cam, 8, rgba8=only.data_ptr(), stream=stream.cuda_stream)
+            stream.synchronize()
+            assert np.array_equal(only.cpu().numpy(), single["rgba8"])

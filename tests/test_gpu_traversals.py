@@ -547,9 +547,14 @@ def test_order_by_the_previous_frame_changes_no_pixel(mode, label, rt_mode, scen
     rt.SendPrimitivesToShader(sc)
     cams = [sc.camera_for(320, 180)] * 3 + [host.camera_orbit(40, 96, 320, 180)] * 2 + [sc.camera_for(200, 120)] * 2 + \
            [sc.camera_for(320, 180)]
-    for k, cam in enumerate(cams):
-        rt.PrepareRenderOpenGL(cam)
-        out = rt.RenderGL(10)
-        ref = rt.RenderGL(10, stats=True)            # (stats: the reference-order kernel)
-        for plane in ("rgb", "primary_id", "final_id", "rgba8"):
-            assert np.array_equal(out[plane].view(np.uint8), ref[plane].view(np.uint8)), (label, k, plane)
+    try:
+        for k, cam in enumerate(cams):
+            # frames 4 and 5 with the feedback switched off (RT_OPTION_FRAME_FEEDBACK: timings independent of the frame before)
+            rt.set_option(rt.OPTION_FRAME_FEEDBACK, 0 if k in (4, 5) else 1)
+            rt.PrepareRenderOpenGL(cam)
+            out = rt.RenderGL(10)
+            ref = rt.RenderGL(10, stats=True)            # (stats: the reference-order kernel)
+            for plane in ("rgb", "primary_id", "final_id", "rgba8"):
+                assert np.array_equal(out[plane].view(np.uint8), ref[plane].view(np.uint8)), (label, k, plane)
+    finally:
+        rt.set_option(rt.OPTION_FRAME_FEEDBACK, 1)
