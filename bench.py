@@ -27,11 +27,21 @@ reference-order kernel outside the timed region; the count is identical to the o
 what the fast kernels actually trace: they leave out shadow rays whose light term is an exact zero
 either way (same pixels), which the reference traces.
 
+`--workload teapottable_sweep256_d8` is BASELINE.json configs[4] as one command: the 256 frames of the camera sweep
+(host.camera_orbit) at 1920x1080, depth 8; a step renders 8 x N consecutive frames of it (8 frames per launch on
+every rank: its bands of them), frame f is assembled on rank f % N by one all-to-all per step, and the steps go
+round the sweep (32 / N steps = one sweep; the default number of steps).
+`--capi-multi --gpus N` measures the multi-GPU render BEHIND the C ABI instead (single process, rt_create_multi over
+devices 0..N-1: one rt_render_device call = one frame, bands on every device, grouped ncclSend/ncclRecv gather on
+the root, device-resident result; `--strong` semantics).  BENCH_MULTI_DEVICES=0,0,0 plays the devices on one GPU.
+
 One JSON line is printed by rank 0 (contract in the task description) with two extra objects:
   roofline      the bound that applies to the dominant kernel (<= 1 by construction), see roofline_of()
   cpu_baseline  the CPU oracle ("port") timed on a bounded sample of the same frame
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import socket
@@ -47,8 +57,7 @@ KERNEL_OF = {1: "k_render<false> (wave-cooperative walk)", 2: "k_render_bvh (per
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 (FMA) x 2.4 GHz
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
-VALU_CYCLES_PER_INST = 2.5   # measured, tools/pk_rate.hip (profiles/r02_pk_rate.txt): a wave64 v_mul/v_fma_f32 issues every
-                             # 2.4-2.65 cycles per SIMD (a packed fp32 instruction every 4.9: two slots)
+N_SIMD_TOTAL = 1024          # 256 CUs x 4 SIMDs: the VALU pipes that profiles/valu_model.json's per-SIMD issue intervals refer to
 BAND_ROWS = 8  # one 8x8 tile row per band: finest interleave of sky / mesh / floor rows over the ranks
 
 WORKLOADS = {
@@ -60,7 +69,10 @@ WORKLOADS = {
     "soup1m_4k_d4": ("Soup", [1_000_000, 10_000, 8], 3840, 2160, 4),
     "soup1m_8k_d4": ("Soup", [1_000_000, 10_000, 8], 7680, 4320, 4),
     "soup100k_1080p_d4": ("Soup", [100_000, 1_000, 8], 1920, 1080, 4),
+    "teapottable_sweep256_d8": ("TeapotTable", None, 1920, 1080, 8),   # configs[4]: the 256-frame orbit, 8 x N frames per step
 }
+SWEEP = "teapottable_sweep256_d8"
+SWEEP_FRAMES, SWEEP_BATCH = 256, 8
 HEADLINE = "teapot_4k_d1"
 EXTRAS = ["teapot_1080p_d1", "testscene1_720p_d10", "teapottable_1080p_d8", "soup100k_1080p_d4", "soup1m_4k_d4"]
 
@@ -149,6 +161,24 @@ def time_single(rt, torch, cam, depth, width, height, steps, warmup):
 
 
 _profiles = None
+_valu_model = None
+_src_sha = None
+
+
+def kernel_src_sha():
+    """Fingerprint of the sources the kernels are built from (the same rule as tools/update_traffic.py, which stores
+    it with every folded PMC run): a committed profile with another fingerprint was measured on other kernels."""
+    global _src_sha
+    if _src_sha is None:
+        h = hashlib.sha256()
+        files = sorted(glob.glob(os.path.join(ROOT, "raytracing_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "raytracing_amd", "csrc", "*.hip")))
+        files += [os.path.join(ROOT, "include", "rt_mi355x.h"), os.path.join(ROOT, "raytracing_amd", "build.py")]
+        for f in files:
+            h.update(os.path.basename(f).encode() + b"\0")
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+        _src_sha = h.hexdigest()[:16]
+    return _src_sha
 
 
 def profile_of(workload):
@@ -161,6 +191,30 @@ def profile_of(workload):
         except (OSError, ValueError):
             _profiles = {}
     return _profiles.get(workload, {})
+
+
+def valu_pipe_seconds(prof):
+    """Seconds of VALU pipe time (summed over the SIMDs) the profiled frame's VALU instructions take at the issue
+    intervals tools/valu_rate.hip measured per instruction KIND on a saturated SIMD (profiles/valu_model.json:
+    plain fp/int 1.2 ns, compares / min / max / conversions / division helpers ~1.8, transcendental 3.4, packed 2.4),
+    weighted per kernel by its static instruction mix; the transcendental share is the dynamic counter's."""
+    global _valu_model
+    if _valu_model is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "valu_model.json")) as f:
+                _valu_model = json.load(f)
+        except (OSError, ValueError):
+            _valu_model = {}
+    ns = _valu_model.get("ns_per_wave_instruction_per_simd", {})
+    total = 0.0
+    for name, k in prof.get("kernels", {}).items():
+        model = _valu_model.get("kernels", {}).get(name)
+        insts = k.get("SQ_INSTS_VALU")
+        if not model or not insts or "trans" not in ns:
+            return None
+        trans = k.get("SQ_INSTS_VALU_TRANS_F32", model["static_transcendental_share"] * insts)
+        total += ((insts - trans) * model["ns_per_non_transcendental_instruction"] + trans * ns["trans"]) * 1e-9
+    return total or None
 
 
 def roofline_of(workload, stats, width, height, ms, traversal, share=1.0):
@@ -178,16 +232,21 @@ def roofline_of(workload, stats, width, height, ms, traversal, share=1.0):
     so they move far fewer bytes than it, and dividing it by the time exceeds every physical bandwidth.
     share: the part of a frame one launch renders (1/N on a rank of a strong-scaled frame)."""
     prof = profile_of(workload)
+    # a profile measured on other kernel sources says nothing about this build's instruction counts or traffic
+    stale = bool(prof) and prof.get("kernel_src_sha") != kernel_src_sha()
     alg_flops = algorithmic_flops(stats) * share
     alg_bytes = algorithmic_bytes(stats, width, height) * share
     tf = alg_flops / (ms * 1e-3) / 1e12
     traffic = prof.get("hbm_bytes_per_launch")
     valu = {"achieved_tflops": round(tf, 2), "peak_tflops": FP32_VECTOR_PEAK_TF, "frac": round(tf / FP32_VECTOR_PEAK_TF, 4),
             "algorithmic_flops_per_launch": int(alg_flops)}
-    if prof.get("SQ_INSTS_VALU"):
-        # issued VALU wave-instructions x the measured issue interval, over the SIMD-cycles of the launch
-        valu["issue_occupancy"] = round(prof["SQ_INSTS_VALU"] * share * VALU_CYCLES_PER_INST / (N_SIMD * ms * 1e-3 * CLOCK_HZ), 3)
-    if prof.get("SQ_THREAD_CYCLES_VALU") and prof.get("SQ_ACTIVE_INST_VALU"):
+    pipe_s = None if stale else valu_pipe_seconds(prof)
+    if pipe_s:
+        # the VALU pipes' time for this frame's instructions (measured per-kind issue intervals) over the SIMD-time of the launch
+        valu["issue_occupancy"] = round(pipe_s * share / (N_SIMD_TOTAL * ms * 1e-3), 3)
+    if not stale and prof.get("SQ_THREAD_CYCLES_VALU") and prof.get("SQ_ACTIVE_INST_VALU"):
+        # (SQ_ACTIVE_INST_VALU counts 1 per instruction and 2 per transcendental one, SQ_THREAD_CYCLES_VALU the same times
+        # the active lanes -- calibrated with tools/valu_rate.hip on full waves: 64 and 128 per instruction)
         valu["active_lanes"] = round(prof["SQ_THREAD_CYCLES_VALU"] / (64.0 * prof["SQ_ACTIVE_INST_VALU"]), 3)
     hbm = None
     if traffic:
@@ -211,6 +270,9 @@ def roofline_of(workload, stats, width, height, ms, traversal, share=1.0):
     r["reference_algorithm_bytes_per_launch"] = int(alg_bytes)
     if prof.get("source"):
         r["pmc_source"] = prof["source"]
+        r["pmc_commit"] = prof.get("git_commit")
+        r["pmc_kernel_ms"] = prof.get("kernel_ms_per_frame")
+    r["pmc_stale"] = stale if prof else None
     return r
 
 
@@ -338,10 +400,89 @@ def measure_extra(rt, torch, host, name):
     big = name.startswith("soup1m")
     ms = time_single(rt, torch, cam, d, w, h, 5 if big else 20, 5)
     trav = rt.scene_info()["traversal"]
-    return {"ms_per_frame": round(ms, 4), "Mrays_per_s": round(total_rays(st) / ms / 1e3, 1),
-            "rays": total_rays(st), "rays_traced": traced_rays(st),
-            "scene_build_s": round(t_build, 2), "upload_s": round(t_up, 2),
-            "roofline": roofline_of(name, st, w, h, ms, trav)}
+    out = {"ms_per_frame": round(ms, 4), "Mrays_per_s": round(total_rays(st) / ms / 1e3, 1),
+           "Mrays_per_s_traced": round(traced_rays(st) / ms / 1e3, 1),
+           "rays": total_rays(st), "rays_traced": traced_rays(st),
+           "scene_build_s": round(t_build, 2), "upload_s": round(t_up, 2),
+           "roofline": roofline_of(name, st, w, h, ms, trav)}
+    if name == "testscene1_720p_d10":
+        # This scene's frames are dealt out in an order ranked from the PREVIOUS launch's wave lifetimes (its root box spans
+        # the view, paths bounce ten times: RT_OPTION_FRAME_FEEDBACK), so ms_per_frame above is the steady state of a
+        # repeated view.  The same frame with the feedback off = the first frame of a view, or any frame after a cut.
+        rt.set_option(rt.OPTION_FRAME_FEEDBACK, 0)
+        cold = time_single(rt, torch, cam, d, w, h, 20, 5)
+        rt.set_option(rt.OPTION_FRAME_FEEDBACK, 1)
+        out["ms_per_frame_is"] = "steady state of a repeated view (tiles ordered by the previous frame's wave lifetimes)"
+        out["ms_first_frame_of_a_view"] = round(cold, 4)
+        out["Mrays_per_s_first_frame_of_a_view"] = round(total_rays(st) / cold / 1e3, 1)
+    return out
+
+
+def capi_multi(args):
+    """`--capi-multi --gpus N`: the multi-GPU render behind the C ABI (rt_create_multi), as the C# host would drive it --
+    one process, one context over N devices, one rt_render_device call = one finished frame on the root device
+    (bands on every device's own stream, all planes in one grouped ncclSend/ncclRecv gather, un-permute on the root).
+    Strong scaling by construction: one frame per step, split over the devices."""
+    import torch
+    from raytracing_amd import RayTracer, host
+    devs = os.environ.get("BENCH_MULTI_DEVICES")   # e.g. "0,0,0": the devices played on one GPU (copies instead of RCCL)
+    devices = [int(x) for x in devs.split(",")] if devs else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but BENCH_MULTI_DEVICES names {len(devices)} devices")
+    scene_name, params, W, H, depth = WORKLOADS[args.workload]
+    if args.workload == SWEEP:
+        raise SystemExit("--capi-multi renders single frames; the sweep is a per-process workload")
+    torch.cuda.set_device(devices[0])
+    sc = host.make_scene(scene_name, params=params)
+    rt = RayTracer(devices)
+    info = rt.multi_info()
+    rt.SendPrimitivesToShader(sc)
+    cam = sc.camera_for(W, H)
+    rt.PrepareRenderOpenGL(cam)
+    st = rt.RenderGL(depth, want=(), stats=True)["stats"]   # reference-order kernel on every device, counters summed
+    out = torch.empty((H, W, 4), dtype=torch.uint8, device=torch.device("cuda", devices[0]))
+    s = torch.cuda.current_stream()
+    for _ in range(max(args.warmup, TUNE_FRAMES)):
+        rt.render_device(cam, depth, rgba8=out.data_ptr(), stream=s.cuda_stream)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(s)
+    for _ in range(args.steps):
+        rt.render_device(cam, depth, rgba8=out.data_ptr(), stream=s.cuda_stream)
+    e1.record(s)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if args.verify:
+        with RayTracer(devices[0]) as one:
+            one.SendPrimitivesToShader(sc)
+            ref = torch.empty_like(out)
+            one.render_device(cam, depth, rgba8=ref.data_ptr(), stream=s.cuda_stream)
+            torch.cuda.synchronize()
+            if not torch.equal(ref, out):
+                raise SystemExit("the frame assembled by the multi-GPU context differs from the single-GPU render")
+    n = len(devices)
+    ms = elapsed / args.steps * 1e3
+    result = {
+        "metric": "Mrays/s (primary+shadow+secondary)", "value": round(total_rays(st) / (elapsed / args.steps) / 1e6, 2),
+        "value_traced": round(traced_rays(st) / (elapsed / args.steps) / 1e6, 2), "unit": "Mrays/s",
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (mesh fixtures of the reference assets / seeded soup, builder-defined scenes)",
+        "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "max_bounces": depth,
+                   "lights": sc.n_lights, "triangles": len(sc.trianglesData), "spheres": len(sc.spheresData),
+                   "frames_per_step": 1, "rays_per_step": total_rays(st), "rays_traced_per_step": traced_rays(st),
+                   "sharding": f"C ABI, one process: rt_create_multi over devices {devices}; {BAND_ROWS}-row bands round-robin, "
+                               f"one frame per rt_render_device call, assembled on device {devices[0]}"},
+        "n_ranks": n, "backend": "rccl (ncclSend/ncclRecv, in-library)" if info["uses_rccl"] else "device-to-device copies (devices played on one GPU)",
+        "n_ranks_rccl": n if info["uses_rccl"] else 0,
+        "ms_per_frame": round(ms, 4), "ms_per_frame_gpu_events": round(e0.elapsed_time(e1) / args.steps, 4),
+        "verified": bool(args.verify),
+        "roofline": roofline_of(args.workload, st, W, H, e0.elapsed_time(e1) / args.steps, rt.scene_info()["traversal"], share=1.0),
+    }
+    result["roofline"]["note"] = "one launch = one frame over all devices; the committed PMC pass (if any) is the single-GPU frame's"
+    print(json.dumps(result), flush=True)
+    rt.close()
 
 
 def main():
@@ -356,8 +497,14 @@ def main():
     ap.add_argument("--no-soup1m", action="store_true", help="skip the 1M-triangle soup among the extras")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--verify", action="store_true", help="check the assembled frames against whole-frame renders")
+    ap.add_argument("--capi-multi", action="store_true",
+                    help="single process: one rt_create_multi context over devices 0..N-1, one rt_render_device call per frame")
     args = ap.parse_args()
+    if args.steps == 50 and args.workload == SWEEP and "--steps" not in " ".join(sys.argv):
+        args.steps = SWEEP_FRAMES // (SWEEP_BATCH * max(args.gpus, 1))   # one pass over the sweep
 
+    if args.capi_multi:
+        return capi_multi(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))   # before anything touches the GPU
 
@@ -390,13 +537,28 @@ def main():
     sc = host.make_scene(scene_name, params=params)
     rt = RayTracer(local_rank)
     rt.SendPrimitivesToShader(sc)
-    n_frames = 1 if args.strong else world
-    cams = orbit_cameras(sc, W, H, n_frames)
+    sweep = args.workload == SWEEP
+    if sweep and (args.strong or SWEEP_FRAMES % (SWEEP_BATCH * world) != 0):
+        raise SystemExit(f"{SWEEP}: weak mode only, and {SWEEP_BATCH} x the number of GPUs must divide {SWEEP_FRAMES}")
+    n_frames = 1 if args.strong else (SWEEP_BATCH * world if sweep else world)
+    if sweep:   # step s renders frames [s * n_frames, (s + 1) * n_frames) of the sweep, round and round
+        all_cams = np.stack([host.camera_orbit(f, SWEEP_FRAMES, W, H) for f in range(SWEEP_FRAMES)])
+        step_cams = [all_cams[k * n_frames:(k + 1) * n_frames] for k in range(SWEEP_FRAMES // n_frames)]
+    else:
+        step_cams = [orbit_cameras(sc, W, H, n_frames)]
+    cams = step_cams[0]
 
-    # rays per step: every frame of the step, counted by the reference-order kernel (untimed)
-    frame_stats = [device_stats(rt, torch, cam, depth) for cam in cams]
+    # rays per step: every frame of the step, counted by the reference-order kernel (untimed); the sweep's steps differ,
+    # so every frame the timed region renders is counted (rank 0 needs them, the others only frame 0's for the roofline)
+    n_distinct = min(len(step_cams), args.steps)
+    counted = [[device_stats(rt, torch, cam, depth) for cam in step_cams[k]] if (rank == 0 or k == 0) else None for k in range(n_distinct)]
+    frame_stats = counted[0]
     rays_per_step = sum(total_rays(s) for s in frame_stats)
     traced_per_step = sum(traced_rays(s) for s in frame_stats)
+    rays_timed = traced_timed = None
+    if rank == 0:
+        rays_timed = sum(sum(total_rays(s) for s in counted[k % n_distinct]) for k in range(args.steps))
+        traced_timed = sum(sum(traced_rays(s) for s in counted[k % n_distinct]) for k in range(args.steps))
     dbg("stats done", rays_per_step)
 
     # ---- timed region: K steps, each = this rank's bands of n_frames frames + ONE collective ----
@@ -409,8 +571,9 @@ def main():
     for _ in range(TUNE_FRAMES):  # the library settles on a kernel for this (scene, local frame size, bounces) before anything is timed
         bufs[0].render(cams, depth)
         torch.cuda.synchronize()
+    timed_step = [0]   # which step of the sweep a timed step renders (warm-up steps render step 0's frames)
 
-    step_no = [0]
+    step_no, timing = [0], [False]
     # N > 1: HIP events around each render launch of the timed region (the first 512 steps), on the launch stream --
     # the roofline's kernel time must not include what the stream waits for between launches (the exchange).  N = 1:
     # nothing lies between the launches, one pair around the whole region measures them without touching the stream.
@@ -420,14 +583,17 @@ def main():
         # step s renders while the exchange of step s-1 is in flight on RCCL's stream
         b, other = bufs[step_no[0] % 2], bufs[(step_no[0] + 1) % 2]
         b.finish()               # this buffer's previous exchange: scanline order on the frame's owner
+        my_cams = step_cams[timed_step[0] % len(step_cams)] if timing[0] else cams
+        if timing[0]:
+            timed_step[0] += 1
         if timed and len(launch_events) < 512:
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record(stream)
-            b.render(cams, depth)
+            b.render(my_cams, depth)
             pair[1].record(stream)
             launch_events.append(pair)
         else:
-            b.render(cams, depth)
+            b.render(my_cams, depth)
         other.wait_gather()      # at most one collective in flight (it has overlapped this step's render)
         b.gather_async()
         step_no[0] += 1
@@ -450,8 +616,10 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(stream)
+    timing[0] = True
     for _ in range(args.steps):
         step(timed=world > 1)
+    timing[0] = False
     drain()
     e1.record(stream)
     fence()
@@ -459,9 +627,27 @@ def main():
     dbg("timed region done", elapsed)
     if args.verify:  # the frames this rank assembled in the last step equal whole-frame renders
         last = bufs[(step_no[0] - 1) % 2]
+        last_cams = step_cams[(timed_step[0] - 1) % len(step_cams)]
+        if sweep:   # frames 0 / 64 / 128 / 192 of the sweep, whichever steps hold them: render those steps once more
+            for f_abs in (0, 64, 128, 192):
+                k = f_abs // n_frames
+                last.render(step_cams[k], depth)
+                last.gather_async()
+                last.finish()
+                torch.cuda.synchronize()
+                for f, frame in last.owned_frames():
+                    if k * n_frames + f != f_abs:
+                        continue
+                    ref = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+                    rt.render_device(step_cams[k][f], depth, rgba8=ref.data_ptr(), stream=stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    if not torch.equal(ref, frame):
+                        raise SystemExit(f"rank {rank}: sweep frame {f_abs} differs from the single-GPU render")
+                    dbg("verified sweep frame", f_abs)
+            last_cams = step_cams[192 // n_frames]
         for f, frame in last.owned_frames():
             ref = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
-            rt.render_device(cams[f], depth, rgba8=ref.data_ptr(), stream=stream.cuda_stream)
+            rt.render_device(last_cams[f], depth, rgba8=ref.data_ptr(), stream=stream.cuda_stream)
             torch.cuda.synchronize()
             if not torch.equal(ref, frame):
                 raise SystemExit(f"rank {rank}: assembled frame {f} differs from the single-GPU render")
@@ -476,7 +662,7 @@ def main():
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = rays_per_step / (elapsed / args.steps) / 1e6
+        value = rays_timed / elapsed / 1e6
         st0 = frame_stats[0]
         trav = rt.scene_info()["traversal"]
         # one launch renders this rank's bands of every frame of the step: n_frames / world frames' worth
@@ -496,8 +682,12 @@ def main():
                        "sharding": ("single GPU, whole frame" if world == 1 else
                                     f"{BAND_ROWS}-row bands round-robin over {world} ranks; " +
                                     ("one frame per step gathered on rank 0" if args.strong else
-                                     f"{world} frames per step, one all-to-all: frame f assembled on rank f"))},
-            "n_ranks_rccl": n_ranks_rccl, "backend": backend if world > 1 else None,
+                                     f"{n_frames} frames per step, one all-to-all: frame f assembled on rank f % {world}")),
+                       "steps_note": (f"step s renders frames [{n_frames} s, {n_frames} (s + 1)) of the {SWEEP_FRAMES}-frame sweep, "
+                                      f"{SWEEP_BATCH} frames per launch; {SWEEP_FRAMES // n_frames} steps = one sweep" if sweep else None)},
+            "value_traced": round(traced_timed / elapsed / 1e6, 2),   # the same, counting only the rays the fast kernels trace
+            "n_ranks": world, "backend": backend if world > 1 else None,
+            "n_ranks_rccl": (world if backend == "nccl" else 0) if world > 1 else 1,
             "ms_per_frame": round(ms_per_step / n_frames, 4),
             "ray_breakdown_frame0": {k: st0[k] for k in ("primary_rays", "secondary_rays", "shadow_rays",
                                                          "shadow_rays_zero_term")},

@@ -75,9 +75,10 @@ class ShardedFrames:
     renders n_frames frames renders every frame's local bands with one launch (up to 8 frames; more go out
     in batches over a few HIP streams) and exchanges them together.  `assemble` says where frames end up:
 
-      "owner"  n_frames == world: frame f is assembled on rank f -- world concurrent gathers, one root each,
-               as ONE all-to-all.  Every rank sends and receives (world-1)/world of a frame per step, whatever
-               the world size (xGMI is point to point: each peer's share travels its own link).
+      "owner"  n_frames a multiple of world: frame f is assembled on rank f % world -- concurrent gathers, one
+               root each, as ONE all-to-all.  Every rank sends and receives (world-1)/world of n_frames / world
+               frames per step, whatever the world size (xGMI is point to point: each peer's share travels its own
+               link).  Inside, the frames are kept in owner-major order so that the chunk for rank d is contiguous.
       "root"   every frame is assembled on rank 0 (one gather): the strong-scaling form, one frame per step.
       "all"    every rank gets every frame (one all-gather); traffic per rank grows with world."""
 
@@ -87,13 +88,16 @@ class ShardedFrames:
         self.rank, self.world, self.band, self.group = rank, world, int(band_rows), group
         if assemble not in ("all", "owner", "root"):
             raise ValueError("assemble must be 'all', 'owner' or 'root'")
-        if assemble == "owner" and self.F != world:
-            raise ValueError("assemble='owner' needs one frame per rank")
+        if assemble == "owner" and self.F % world != 0:
+            raise ValueError("assemble='owner' needs a multiple of `world` frames")
         self.assemble = assemble
+        # slot j of the local buffer holds frame order[j]: owner-major for "owner" (rank d's frames d, d + world, ...)
+        per = self.F // world if assemble == "owner" else self.F
+        self.order = [i * world + d for d in range(world) for i in range(per)] if assemble == "owner" and world > 1 else list(range(self.F))
         dev = device if device is not None else torch.device("cuda", rt.device_id)
         self.pr = padded_rows(self.H, self.band, world)
         self.local = torch.zeros((self.F, self.pr, self.W, 4), dtype=torch.uint8, device=dev)
-        n_mine = {"all": self.F, "owner": 1, "root": self.F if rank == 0 else 0}[assemble]
+        n_mine = {"all": self.F, "owner": self.F // world, "root": self.F if rank == 0 else 0}[assemble]
         self.n_mine = n_mine
         # what arrives here: [source rank][frame of mine][padded rows][W] (owner: one frame, root: rank 0 only)
         self.gathered = torch.empty((world, max(n_mine, 1), self.pr, self.W, 4), dtype=torch.uint8, device=dev)
@@ -111,7 +115,7 @@ class ShardedFrames:
     def owned_frames(self):
         """(frame index, assembled [H, W, 4] tensor) of the frames this rank holds after finish()."""
         if self.assemble == "owner" and self.world > 1:
-            return [(self.rank, self.frames[0])]
+            return [(i * self.world + self.rank, self.frames[i]) for i in range(self.n_mine)]
         return [(f, self.frames[f]) for f in range(self.n_mine)]
 
     def render(self, cameras, max_bounces):
@@ -120,6 +124,7 @@ class ShardedFrames:
         alternating over the streams so that the tail of one launch overlaps the head of the next."""
         out = self.local if self.world > 1 else self.frames  # a single rank renders straight into the frames
         stride = out.stride(0) // 4  # pixels between consecutive frames
+        cameras = np.ascontiguousarray(np.asarray(cameras, dtype=np.float32)[:self.F][self.order])
         batches = [(f0, min(f0 + 8, self.F)) for f0 in range(0, self.F, 8)]
         if len(batches) == 1 or not self.streams:
             self.rt.render_frames_device(cameras[:self.F], max_bounces, stride, rgba8=out.data_ptr(), band_rows=self.band,
