@@ -8,6 +8,8 @@
 set -u
 WL=$1; TAG=$2; FRAMES=${3:-10}
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+# the same program without a profiler first: what the profiler itself costs the kernels (clock, serialisation) is stated, not hidden
+timeout -k 10 300 python3 tools/profile_workload.py $WL $FRAMES > "$OUT/run_unprofiled.txt" 2> "$OUT/run_unprofiled.err" || { echo plain run failed; tail -5 "$OUT/run_unprofiled.err"; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 tools/profile_workload.py $WL $FRAMES > "$OUT/run.txt" 2> "$OUT/prof.err" || { echo rocprof failed; tail -5 "$OUT/prof.err"; exit 1; }
 cat "$OUT/run.txt"
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
@@ -18,4 +20,4 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum 
     timeout -s KILL 240 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc_$name" -- python3 tools/profile_workload.py $WL $FRAMES > "$OUT/pmc_$name.txt" 2> "$OUT/pmc_$name.err" || { echo "pmc $name failed"; tail -5 "$OUT/pmc_$name.err"; exit 1; }
 done
 python tools/pmc_summary.py "$OUT"/pmc_* > "$OUT/pmc_summary.txt"
-python tools/update_traffic.py --dry-run $WL "$OUT" $FRAMES
+python tools/update_traffic.py --dry-run $WL "$OUT" $FRAMES > "$OUT/fold_preview.json" 2>&1 || true

@@ -39,14 +39,14 @@ for path in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True)
             k = row["Kernel_Name"]
             if any(s in k for s in FAST):
                 tot[row["Counter_Name"]] += float(row["Counter_Value"])
-                per_kernel[k.split("(")[0].replace("void rtd::", "")][row["Counter_Name"]] += float(row["Counter_Value"])
+                per_kernel[k.split("(")[0].replace("void ", "").replace("rtd::", "")][row["Counter_Name"]] += float(row["Counter_Value"])
 kernel_ns, calls = defaultdict(float), defaultdict(int)
 for path in glob.glob(src + "/prof/**/*kernel_stats.csv", recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row["Name"]
             if any(s in k for s in FAST):
-                kk = k.split("(")[0].replace("void rtd::", "")
+                kk = k.split("(")[0].replace("void ", "").replace("rtd::", "")
                 kernel_ns[kk] += float(row["TotalDurationNs"])
                 calls[kk] += int(row["Calls"])
 per_frame = {c: v / frames for c, v in tot.items()}
@@ -70,6 +70,16 @@ for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_ACTIVE_INST_VALU", "SQ
         entry[c] = round(per_frame[c], 1)
 if "--memory-bound" in sys.argv:
     entry["memory_bound"] = True
+for fname, key in (("run_unprofiled.txt", "ms_per_frame_unprofiled"), ("run.txt", "ms_per_frame_under_kernel_trace")):
+    try:
+        with open(os.path.join(src, fname)) as f:
+            for line in f:
+                if "ms_per_frame=" in line:
+                    entry[key] = float(line.split("ms_per_frame=")[1].split()[0])   # (the second half of the frames, synchronised per frame)
+    except OSError:
+        pass
+if "ms_per_frame_unprofiled" in entry and "ms_per_frame_under_kernel_trace" in entry:
+    entry["profiler_overhead"] = round(entry["ms_per_frame_under_kernel_trace"] / entry["ms_per_frame_unprofiled"] - 1.0, 3)
 entry["kernel_src_sha"] = kernel_src_sha(ROOT)   # (fold a run into profiles/ before touching the sources again)
 try:
     entry["git_commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
