@@ -80,7 +80,13 @@ void rt_destroy(rt_ctx* ctx);
  *                    peer's bands travel its own xGMI link) and restores scanline order there: one call = one
  *                    finished frame, as the reference's draw; results are those of a single-GPU context,
  *   rt_set_option / rt_get_scene_info / rt_last_error / rt_destroy act on the whole context.
- * The device-resident entry points (rt_render_device*, rt_unpermute_*) address the ROOT device only.
+ *   rt_render_device with rank 0, world 1 and neither d_bounces nor d_stats does the same and leaves the assembled
+ *                    planes in the caller's buffers on the ROOT device (all requested planes in one grouped
+ *                    exchange), asynchronously on `stream`, a stream of the root device,
+ * The other device-resident entry points (rt_render_device with a band split, rt_render_frames_device,
+ * rt_render_device_noalloc, rt_unpermute_*) address the ROOT device only.
+ * The exchange over RCCL has run with one device only (and with one device named several times): UNVERIFIED on
+ * hardware for n > 1 distinct devices.
  * Single process, one host thread; RCCL (librccl.so) is loaded when the first such context is created
  * (ncclCommInitAll).  A list that names one device several times is accepted for testing: the ranks are then
  * played on that GPU and the bands move with device-to-device copies instead of RCCL. */
@@ -182,7 +188,8 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
                      int rank, int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id,
                      int32_t* d_final_id, int32_t* d_bounces, rt_stats* d_stats, void* stream);
 
-/* rt_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight
+/* rt_render_device for callers that cannot allocate device memory: code under HIP graph capture (the call does no
+ * allocation and no event operation: tests/test_zz_no_alloc.py records one render into a graph and replays it), tight
  * serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its frame buffer and
  * every SSBO are allocated by the GL driver, RayTracer.cs:1007-1045).  Same arguments, same results as
  * rt_render_device with flags = RT_RENDER_DEFAULT and no d_stats; the difference is where the staged
@@ -194,8 +201,8 @@ int rt_render_device(rt_ctx* ctx, const float camera[14], int max_bounces, int f
  * array is rejected with RT_ERR_TOO_LARGE before anything is launched; the megakernels (small scenes) keep no
  * such state and accept any size.  AUTO does not time mid-sized scenes here (a verdict rt_render_device
  * measured earlier is reused, otherwise the megakernel renders).  All calls on one GPU share that GPU's
- * array: calls that overlap on one GPU -- two contexts, or this context on two streams without the
- * library's own chaining, which only orders renders of ONE context -- race. */
+ * array: calls that overlap on one GPU -- two contexts, this context on two streams, replays of a graph beside
+ * other renders -- race; the library does not order these calls, the caller does. */
 #define RT_NOALLOC_SCRATCH_BYTES (96u << 20)
 int rt_render_device_noalloc(rt_ctx* ctx, const float camera[14], int max_bounces, int band_rows, int rank,
                              int world, float* d_rgb, uint8_t* d_rgba8, int32_t* d_primary_id,
