@@ -134,6 +134,12 @@ enum {
                                 frames of a view are faster than its first (TestScene1 720p depth 10: 0.31 against 0.40 ms).
                                 0: every frame is dealt out in the fixed order -- what a caller sets who wants timings that
                                 do not depend on the frame before.  Pixels never depend on it */
+    RT_OPTION_BIN_PATHS = 10, /* staged pipeline only.  n > 0: the lists of continuing paths that iterations >= n read are
+                                sorted by the cell of the paths' new origin and their direction octant (counting sort on
+                                the device, two small kernels per bounce) before they are traced.  0 (default): lists stay
+                                in compaction order.  Measured on the 1M-triangle soup at 4K: neither gains nor loses
+                                (47.7 ms both ways, profiles/r03_soup1m_binning_per_bounce.txt), hence off.  Pixels never
+                                depend on it; rt_render_device_noalloc ignores it */
     RT_OPTION_GPU_FLATTEN_MIN = 8 /* accel arrays of at least this many floats (default 65536) are validated and
                                 flattened on the GPU, level by level (bit-identical to the host's walk, which smaller
                                 arrays take and which still words every refusal); -1: never */

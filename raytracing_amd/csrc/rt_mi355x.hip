@@ -104,6 +104,8 @@ struct rt_ctx {
     bool allow_lds = false;     // RT_OPTION_USE_LDS: opt-in, measured slower than the L2-resident walk
     // path state of the wavefront pipeline (rt_wavefront.h; grow only)
     DevBuf wf_org, wf_dir, wf_mult, wf_final, wf_list0, wf_list1, wf_blocked, wf_counters;
+    DevBuf wf_list_tmp, wf_keys, wf_bins;  // binning of the continuing paths (k_wf_bin_*)
+    int wf_bin_from = 0;  // lists of iterations >= this are sorted by origin cell (0: none)
     unsigned char* noalloc_scratch = nullptr;  // this device's address of `scratch` (hipGetSymbolAddress, rt_create)
     int wf_min_nodes = 1000;   // scenes with at least this many flat nodes get the tight tree and are candidates for
                                // the staged pipeline under AUTO (decided by measurement, tune_begin)
@@ -285,6 +287,19 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st, bool noal
         a.blocked = (unsigned char*)ctx->wf_blocked.p;
         a.counters = (uint32_t*)ctx->wf_counters.p;
     }
+    // (the static array's layout and frame limit stay as documented: a noalloc render does not bin)
+    a.bin_from = noalloc || ctx->wf_bin_from > r.max_bounces ? 0 : ctx->wf_bin_from;
+    a.list_tmp = a.keys = a.bins = nullptr;
+    if (a.bin_from > 0) {
+        if ((rc = ensure(ctx, ctx->wf_list_tmp, n_px * 4)) || (rc = ensure(ctx, ctx->wf_keys, n_px * 4)) ||
+            (rc = ensure(ctx, ctx->wf_bins, (size_t)WF_BINS * 4)))
+            return rc;
+        a.list_tmp = (uint32_t*)ctx->wf_list_tmp.p, a.keys = (uint32_t*)ctx->wf_keys.p, a.bins = (uint32_t*)ctx->wf_bins.p;
+        for (int c = 0; c < 3; c++) {
+            const float e = a.scene.extent[c];
+            a.bin_scale[c] = e > 0 && e < 1e30f ? (float)(1 << WF_BIN_BITS) / (2 * e) : 0.0f;
+        }
+    }
     // (noalloc: no event work at all -- the caller orders its calls on one GPU, rt_mi355x.h -- so the whole render is
     // memset + kernel launches on `st` and can be recorded into a HIP graph)
     if (!noalloc && (rc = chain_begin(ctx, st))) return rc;
@@ -303,7 +318,13 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st, bool noal
                            st, a);
         if (a.n_lights > 0)
             hipLaunchKernelGGL(unb ? k_wf_any<true> : k_wf_any<false>, dim3(trace_grid), dim3(64), lds, st, a);
+        const bool bin = a.bin_from > 0 && i + 1 >= a.bin_from && i < r.max_bounces;  // this iteration's output list
+        if (bin) HIP_TRY(ctx, hipMemsetAsync(a.bins, 0, (size_t)WF_BINS * 4, st));
         hipLaunchKernelGGL(k_wf_shade, dim3(shade_grid), dim3(256), 0, st, a);
+        if (bin) {
+            hipLaunchKernelGGL(k_wf_bin_scan, dim3(1), dim3(1024), 0, st, a);
+            hipLaunchKernelGGL(k_wf_bin_scatter, dim3(shade_grid), dim3(256), 0, st, a);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     return noalloc ? (int)RT_OK : chain_end(ctx, st);
@@ -364,6 +385,7 @@ int rt_create(int device_id, rt_ctx** out) {
         const int t = atoi(v);
         if (t >= 1 && t <= 64) ctx->wf_waves_per_cu = t;
     }
+    if (const char* v = getenv("RT_WF_BIN_FROM")) ctx->wf_bin_from = std::max(atoi(v), 0);  // development
     if (const char* v = getenv("RT_PRIORITISE")) ctx->prioritise = atoi(v) != 0;
     if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development overrides
     if (const char* v = getenv("RT_GPU_FLATTEN_MIN")) ctx->gpu_flatten_min = atoi(v);
@@ -408,7 +430,8 @@ void rt_destroy(rt_ctx* ctx) {
         for (hipEvent_t e : pair)
             if (e) (void)hipEventDestroy(e);
     DevBuf* wf[] = {&ctx->wf_org,   &ctx->wf_dir,   &ctx->wf_mult,    &ctx->wf_final,
-                    &ctx->wf_list0, &ctx->wf_list1, &ctx->wf_blocked, &ctx->wf_counters};
+                    &ctx->wf_list0, &ctx->wf_list1, &ctx->wf_blocked, &ctx->wf_counters,
+                    &ctx->wf_list_tmp, &ctx->wf_keys, &ctx->wf_bins};
     for (DevBuf* b : wf) release(*b);
     DevBuf* all[] = {&ctx->geom,       &ctx->plane_geom, &ctx->tri_slot_id, &ctx->sphere_slot_id, &ctx->spheres_aos,
                      &ctx->planes_aos, &ctx->tris_aos,   &ctx->lights,      &ctx->ticket,         &ctx->fb_rgb,
@@ -444,6 +467,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
         case RT_OPTION_FRAME_FEEDBACK:
             ctx->use_heat = value != 0;
             ctx->heat_valid = false;
+            return RT_OK;
+        case RT_OPTION_BIN_PATHS:
+            if (value < 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "first sorted iteration must be >= 0 (0: no binning)");
+            ctx->wf_bin_from = value;
             return RT_OK;
         case RT_OPTION_GPU_FLATTEN_MIN:
             if (value < -1) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "GPU flatten threshold must be >= -1");

@@ -45,7 +45,50 @@ struct WfArgs {
     uint32_t* list[2];       // active pixels of odd / even iterations >= 1
     unsigned char* blocked;  // [active index j * n_lights + l]: shadow ray result of this iteration
     uint32_t* counters;      // per iteration i: [4i] active paths, [4i+1] closest fetch head, [4i+2] any-hit fetch head
+    // binning of the continuing paths by the cell of their new origin (k_wf_bin_scan / k_wf_bin_scatter below):
+    // lists of iterations >= bin_from are sorted (0: none)
+    int bin_from;
+    float bin_scale[3];  // cells per unit length of each axis over [-extent, +extent]
+    uint32_t* list_tmp;  // the unsorted list k_wf_shade appends to
+    uint32_t* keys;      // [entry of list_tmp]: its cell
+    uint32_t* bins;      // [WF_BINS]: counts, then running offsets
 };
+constexpr int WF_BIN_BITS = 4;                    // cells per axis = 16
+constexpr int WF_BINS = 8 << (3 * WF_BIN_BITS);   // x 8 direction octants  // Morton-ordered cells of the root box
+__device__ __forceinline__ bool wf_binned(const WfArgs& a, int iter) { return a.bin_from > 0 && iter >= a.bin_from; }
+__device__ __forceinline__ uint32_t wf_spread3(uint32_t v) {  // 5 bits -> every third bit
+    v = (v | (v << 8)) & 0x0000F00Fu;
+    v = (v | (v << 4)) & 0x000C30C3u;
+    v = (v | (v << 2)) & 0x00249249u;
+    return v;
+}
+// arr[key] += 1 for every active lane, one atomic per distinct key of the wave (hit points of a plane outside the root
+// box all fall into a few border cells: lane-by-lane atomics on one address serialise at ~12 ns each); returns the
+// lane's place: the old value plus its rank among the wave's lanes with the same key
+__device__ __forceinline__ uint32_t wf_wave_add(uint32_t* arr, uint32_t key, bool active) {
+    uint32_t place = 0;
+    unsigned long long todo = __ballot(active);
+    const int lane = (int)__lane_id();
+    while (todo) {
+        const int leader = __ffsll(todo) - 1;
+        const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
+        const unsigned long long same = __ballot(active && key == k) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(arr + k, (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if ((same >> lane) & 1ull) place = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return place;
+}
+__device__ __forceinline__ uint32_t wf_cell(const WfArgs& a, V3 x) {
+    const int top = (1 << WF_BIN_BITS) - 1;
+    // (points of the planes lie outside the root box: clamped to the border cells; NaN converts to 0)
+    const int cx = min(max((int)((x.x + a.scene.extent[0]) * a.bin_scale[0]), 0), top);
+    const int cy = min(max((int)((x.y + a.scene.extent[1]) * a.bin_scale[1]), 0), top);
+    const int cz = min(max((int)((x.z + a.scene.extent[2]) * a.bin_scale[2]), 0), top);
+    return wf_spread3((uint32_t)cx) | (wf_spread3((uint32_t)cy) << 1) | (wf_spread3((uint32_t)cz) << 2);
+}
 
 constexpr uint32_t WF_NO_HIT = 3u << 28;
 __device__ __forceinline__ uint32_t wf_pack_hit(int kind, int index) { return ((uint32_t)kind << 28) | (uint32_t)(index & 0xFFFFFF); }
@@ -479,6 +522,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const WfArgs a) {
             p = (int)wf_list_in(a)[j];
         }
         bool continues = false;
+        uint32_t cell = 0;
         if (p >= 0) {
             const float4 q0 = a.org_t[p], q1 = a.dir_hit[p];
             const V3 rayOrigin = v3(q0.x, q0.y, q0.z), rayDirection = v3(q1.x, q1.y, q1.z);
@@ -509,6 +553,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const WfArgs a) {
                 a.mult_b[p] = make_float4(mult.x, mult.y, mult.z, 0);
                 a.final_[p] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0);
                 continues = true;
+                if (wf_binned(a, a.iter + 1)) cell = (wf_cell(a, hitPos) << 3) | (refl.x < 0 ? 1u : 0u) | (refl.y < 0 ? 2u : 0u) | (refl.z < 0 ? 4u : 0u);
             } else {
                 PixelOut out;
                 out.primary_id = 0;
@@ -535,8 +580,53 @@ __global__ __launch_bounds__(256) void k_wf_shade(const WfArgs a) {
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(a.counters + 4 * (a.iter + 1), (uint32_t)__popcll(mask));
             base = (uint32_t)__shfl((int)base, leader, 64);
-            if (continues) wf_list_out(a)[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)p;
+            const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (wf_binned(a, a.iter + 1)) {
+                if (continues) a.list_tmp[at] = (uint32_t)p, a.keys[at] = cell;
+                wf_wave_add(a.bins, cell, continues);
+            } else if (continues) {
+                wf_list_out(a)[at] = (uint32_t)p;
+            }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Binning of the continuing paths (not in the reference, changes no pixel: every stage treats the paths of
+// a list independently).  The list k_wf_shade appends to is in compaction order: after the first bounce of
+// a scene of small mirrors neighbouring entries start anywhere in the scene.  A counting sort by the cell
+// of the new origin (32^3 cells of the root box in Morton order) makes the entries a wave draws together
+// neighbours in space: their shadow rays to one light are near-parallel again, and their bounce rays at
+// least start in the same leaves.  k_wf_shade counts the cells as it appends; one workgroup turns the
+// counts into offsets; the scatter hands out places with one returning atomic per path.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_wf_bin_scan(const WfArgs a) {
+    __shared__ uint32_t part[1024];
+    constexpr int PER = WF_BINS / 1024;
+    const int t = (int)threadIdx.x;
+    uint32_t v[PER], sum = 0;
+    for (int k = 0; k < PER; k++) v[k] = a.bins[t * PER + k], sum += v[k];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan of the 1024 partial sums
+        const uint32_t add = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int k = 0; k < PER; k++) a.bins[t * PER + k] = run, run += v[k];
+}
+__global__ __launch_bounds__(256) void k_wf_bin_scatter(const WfArgs a) {
+    const uint32_t total = a.counters[4 * (a.iter + 1)];
+    uint32_t* const out = wf_list_out(a);
+    // (whole waves stay in the loop: the places are handed out per wave)
+    for (uint32_t j0 = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); j0 < total; j0 += gridDim.x * blockDim.x) {
+        const uint32_t j = j0 + (threadIdx.x & 63u);
+        const bool in = j < total;
+        const uint32_t key = in ? a.keys[j] : 0u;
+        const uint32_t place = wf_wave_add(a.bins, key, in);
+        if (in) out[place] = a.list_tmp[j];
     }
 }
 

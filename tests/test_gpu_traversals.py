@@ -558,3 +558,26 @@ def test_order_by_the_previous_frame_changes_no_pixel(mode, label, rt_mode, scen
                 assert np.array_equal(out[plane].view(np.uint8), ref[plane].view(np.uint8)), (label, k, plane)
     finally:
         rt.set_option(rt.OPTION_FRAME_FEEDBACK, 1)
+
+
+@pytest.mark.parametrize("name,params,depth", [("TestScene1", None, 10), ("TeapotTable", None, 8), ("Soup", [20000, 200, 8], 4)])
+def test_binned_path_lists_change_no_pixel(name, params, depth, rt_mode, scene_of):
+    """RT_OPTION_BIN_PATHS sorts the lists of continuing paths by origin cell and direction octant between the bounces
+    of the staged pipeline (counting sort on the device): every plane must stay bit-identical to the unsorted run's,
+    from whichever bounce the sorting starts, and match the oracle."""
+    rt = rt_mode
+    sc = scene_of(name, params)
+    _set_mode(rt, 4)
+    cam = sc.camera_for(200, 120)
+    try:
+        rt.set_option(rt.OPTION_BIN_PATHS, 0)
+        base = _render(rt, sc, cam, depth)
+        assert_frame_matches(base, oracle_render(sc, cam, depth, threads=16), name + " unsorted")
+        for first in (1, 2, depth, depth + 1):
+            rt.set_option(rt.OPTION_BIN_PATHS, first)
+            out = _render(rt, sc, cam, depth)
+            for plane in ("primary_id", "final_id"):
+                assert np.array_equal(out[plane], base[plane]), (name, first, plane)
+            assert np.array_equal(out["rgb"].view(np.uint32), base["rgb"].view(np.uint32)), (name, first)
+    finally:
+        rt.set_option(rt.OPTION_BIN_PATHS, 0)
