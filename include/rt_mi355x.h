@@ -140,6 +140,11 @@ enum {
                                 in compaction order.  Measured on the 1M-triangle soup at 4K: neither gains nor loses
                                 (47.7 ms both ways, profiles/r03_soup1m_binning_per_bounce.txt), hence off.  Pixels never
                                 depend on it; rt_render_device_noalloc ignores it */
+    RT_OPTION_GPU_BUILD_MIN = 11, /* scenes whose two derived trees (re-treed leaves, tight tree) have at least this many
+                                items together (default 20000) get them built on the GPU: binned SAH, large nodes level by
+                                level, subtrees of <= 64 items by one wave each -- node arrays bit-identical to the host
+                                builder's (rt_check_gpu_build), which smaller scenes, multi-GPU contexts and trees the
+                                device declines still take.  -1: never */
     RT_OPTION_GPU_FLATTEN_MIN = 8 /* accel arrays of at least this many floats (default 65536) are validated and
                                 flattened on the GPU, level by level (bit-identical to the host's walk, which smaller
                                 arrays take and which still words every refusal); -1: never */
@@ -290,6 +295,15 @@ int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, in
  * the host's message -- or RT_ERR_DEVICE with the first difference in err / rt_last_error.  Used by the tests. */
 int rt_check_gpu_flatten(rt_ctx* ctx, const float* accel, int64_t accel_len, int n_spheres, int n_triangles, char* err,
                          size_t err_cap);
+
+/* Self-check of the GPU tree builds (RT_OPTION_GPU_BUILD_MIN): builds the re-treed leaves and the tight tree of the
+ * scene (tight_min_nodes as in rt_check_scene) on the host threads and on ctx's GPU, whatever their size, and compares
+ * the node arrays, the depths, the second root holder and the 16-bit grid form bit for bit.  Returns 1 (identical), 0
+ * (the device declined a tree: a large node of coincident centroids, which it leaves to the host's median split), a
+ * refusal of the accel array as rt_upload_scene words it, or RT_ERR_DEVICE with the first difference in err /
+ * rt_last_error.  Used by the tests.  No counterpart in the reference (its tree arrives built, RTree.cs:180-377). */
+int rt_check_gpu_build(rt_ctx* ctx, const void* spheres, int n_spheres, const void* triangles, int n_triangles, const float* accel,
+                       int64_t accel_len, int tight_min_nodes, char* err, size_t err_cap);
 
 /* Per-function device evaluators of the four intersection routines, one case per element
  * (raytracer_fs.glsl:134-161, 93-113, 114-120, 121-131).  Host arrays; used by the parity

@@ -60,6 +60,7 @@ DEVICE_API = {
     "rt_check_accel": (_I, [_VP, _I64, _I, _I, C.POINTER(rt_scene_info), C.c_char_p, C.c_size_t]),
     "rt_check_scene": (_I, [_VP, _I, _VP, _I, _VP, _I64, _I, C.POINTER(rt_scene_info), C.c_char_p, C.c_size_t]),
     "rt_check_gpu_flatten": (_I, [_VP, _VP, _I64, _I, _I, C.c_char_p, C.c_size_t]),
+    "rt_check_gpu_build": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I64, _I, C.c_char_p, C.c_size_t]),
     "rt_eval_box": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
     "rt_eval_sphere": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
     "rt_eval_plane": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP]),

@@ -39,6 +39,12 @@
 
 #include "rt_flatten.h"
 
+#if defined(__HIPCC__)
+#define RT_BVH_HD __host__ __device__
+#else
+#define RT_BVH_HD
+#endif
+
 namespace rtb {
 
 // A few worker threads whose failures come back to the caller.  A body that throws (std::bad_alloc on a
@@ -124,25 +130,91 @@ struct Item {
     uint32_t ref;
     float weight;  // primitives in the leaf
 };
+// (RT_BVH_HD: the device builder, rt_gpu_bvh.h, runs the same arithmetic -- binary64 without contraction, so the two
+// builders decide every split alike)
 struct Box {
     float lo[3], hi[3];
-    void reset() {
+    RT_BVH_HD void reset() {
         for (int k = 0; k < 3; k++) lo[k] = 3.402823466e+38f, hi[k] = -3.402823466e+38f;
     }
-    void grow(const float* l, const float* h) {
-        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], l[k]), hi[k] = std::max(hi[k], h[k]);
+    RT_BVH_HD void grow(const float* l, const float* h) {
+        for (int k = 0; k < 3; k++) lo[k] = l[k] < lo[k] ? l[k] : lo[k], hi[k] = hi[k] < h[k] ? h[k] : hi[k];
     }
-    double half_area() const {
+    RT_BVH_HD double half_area() const {
         const double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
         return x * y + y * z + z * x;
     }
 };
+constexpr int BINS = 16;
+// bin of an item (its box along one axis) among BINS equal bins over the centroid bounds [lo, lo + BINS / scale]
+RT_BVH_HD inline int bin_index(float item_lo, float item_hi, float lo, double scale) {
+    const double c = 0.5f * item_lo + 0.5f * item_hi;
+    int k = (int)((c - lo) * scale);
+    return k < 0 ? 0 : (k >= BINS ? BINS - 1 : k);
+}
+RT_BVH_HD inline double bin_scale(float cb_lo, float cb_hi) {
+    const double ext = (double)cb_hi - cb_lo;
+    return ext > 0 ? BINS / ext : 0;
+}
+// The binned search: the cheapest of the <= 3 x (BINS - 1) splits between bins whose sides are non-empty and hold at
+// most child_cap items each (axis -1: none).  bin_at(axis, k, &box, &weight, &count) reads one bin.  Ties keep the
+// first candidate in (axis, bin) order.
+struct SplitChoice {
+    int axis, bin;
+};
+// One axis of the search (called for axis 0, 1, 2 in that order; *best_cost starts at 1e300, *best at {-1, -1}).
+template <class BinAt>
+RT_BVH_HD inline void split_axis(int ax, double scale_ax, size_t n, size_t child_cap, BinAt&& bin_at, double* best_cost, SplitChoice* best) {
+    if (!(scale_ax > 0)) return;
+    double right_cost[BINS];
+    Box acc, bb;
+    double bw;
+    size_t bn;
+    acc.reset();
+    double w = 0;
+    for (int k = BINS - 1; k > 0; k--) {
+        bin_at(ax, k, &bb, &bw, &bn);
+        if (bn) acc.grow(bb.lo, bb.hi);
+        w += bw;
+        right_cost[k] = w > 0 ? acc.half_area() * w : 0;
+    }
+    acc.reset();
+    w = 0;
+    size_t nl = 0;
+    for (int k = 0; k + 1 < BINS; k++) {
+        bin_at(ax, k, &bb, &bw, &bn);
+        if (bn) acc.grow(bb.lo, bb.hi);
+        w += bw;
+        nl += bn;
+        if (nl == 0 || nl == n) continue;
+        if (nl > child_cap || n - nl > child_cap) continue;  // would break the level bound
+        const double cost = acc.half_area() * w + right_cost[k + 1];
+        if (cost < *best_cost) *best_cost = cost, best->axis = ax, best->bin = k;
+    }
+}
+template <class BinAt>
+RT_BVH_HD inline SplitChoice choose_split(const double* scale, size_t n, size_t child_cap, BinAt&& bin_at) {
+    SplitChoice best{-1, -1};
+    double best_cost = 1e300;
+    for (int ax = 0; ax < 3; ax++) split_axis(ax, scale[ax], n, child_cap, bin_at, &best_cost, &best);
+    return best;
+}
+// items a child of a node at `level` may hold so that its subtree still fits the MAX_LEVELS bound (n <= 2^room)
+RT_BVH_HD inline size_t child_capacity(int level) {
+    const int room = 32 /* MAX_LEVELS */ - level;
+    return (room - 1 >= 31) ? (size_t)1 << 31 : (size_t)1 << (room - 1);
+}
+// order of two items with coincident centroids, and of equal keys of the median split: by ref (unique per item of a
+// tree), so that a tree does not depend on the order its items arrive in -- the device builder partitions with
+// atomics (rt_gpu_bvh.h)
+RT_BVH_HD inline bool median_before(float key_x, uint32_t ref_x, float key_y, uint32_t ref_y) {
+    return key_x < key_y || (key_x == key_y && ref_x < ref_y);
+}
 
 struct Builder {
     std::vector<Item>& items;
     Bvh& out;
     std::atomic<int> levels{0};
-    static constexpr int BINS = 16;
     static constexpr size_t FORK_MIN = 1 << 15;   // subtrees at least this large may be built by another thread
     static constexpr size_t SWEEP_MIN = 1 << 17;  // nodes at least this large are binned by several threads
     struct Bins {
@@ -177,12 +249,14 @@ struct Builder {
             // half of all nodes: what the binned search below decides for two items, without the bins -- the first
             // axis along which the centroids differ separates them (every such split costs the same), lower first
             Item &p = items[b], &q = items[b + 1];
-            for (int k = 0; k < 3; k++) {
+            bool decided = false;
+            for (int k = 0; k < 3 && !decided; k++) {
                 const float cp = 0.5f * p.lo[k] + 0.5f * p.hi[k], cq = 0.5f * q.lo[k] + 0.5f * q.hi[k];
                 if (cp == cq) continue;
                 if (cq < cp) std::swap(p, q);
-                break;
+                decided = true;
             }
+            if (!decided && q.ref < p.ref) std::swap(p, q);  // coincident centroids: by ref (median_before)
             for (int seen = levels.load(); level + 1 > seen && !levels.compare_exchange_weak(seen, level + 1);) {
             }
             Node& nd = out.nodes[base];
@@ -192,7 +266,8 @@ struct Builder {
             box->grow(q.lo, q.hi);
             return base | ((ref_nocull(p.ref) || ref_nocull(q.ref)) ? NOCULL : 0u);
         }
-        const size_t child_cap = (room - 1 >= 31) ? (size_t)1 << 31 : (size_t)1 << (room - 1);
+        const size_t child_cap = child_capacity(level);
+        (void)room;
         // The passes over a large node's items (centroid bounds, then the bins of all three axes in one sweep) are
         // cut into ranges for the threads this subtree may still fork: box unions are min/max and the bin weights
         // are small integers summed in double, so the result does not depend on how the range was cut.
@@ -221,10 +296,7 @@ struct Builder {
             for (const Box& p : part) cb.grow(p.lo, p.hi);
         }
         double scale[3];
-        for (int ax = 0; ax < 3; ax++) {
-            const double ext = (double)cb.hi[ax] - cb.lo[ax];
-            scale[ax] = ext > 0 ? BINS / ext : 0;
-        }
+        for (int ax = 0; ax < 3; ax++) scale[ax] = bin_scale(cb.lo[ax], cb.hi[ax]);
         std::vector<Bins> bins(helpers);
         sweep([&](int t, size_t first, size_t last) {
             Bins& bs = bins[t];
@@ -239,35 +311,10 @@ struct Builder {
                 }
         });
         for (int t = 1; t < helpers; t++) bins[0].add(bins[t]);
-        int best_axis = -1, best_bin = -1;
-        double best_cost = 1e300;
-        for (int ax = 0; ax < 3; ax++) {
-            if (!(scale[ax] > 0)) continue;
-            const Box* bb = bins[0].bb[ax];
-            const double* bw = bins[0].bw[ax];
-            const size_t* bn = bins[0].bn[ax];
-            double right_cost[BINS];
-            Box acc;
-            acc.reset();
-            double w = 0;
-            for (int k = BINS - 1; k > 0; k--) {
-                if (bn[k]) acc.grow(bb[k].lo, bb[k].hi);
-                w += bw[k];
-                right_cost[k] = w > 0 ? acc.half_area() * w : 0;
-            }
-            acc.reset();
-            w = 0;
-            size_t nl = 0;
-            for (int k = 0; k + 1 < BINS; k++) {
-                if (bn[k]) acc.grow(bb[k].lo, bb[k].hi);
-                w += bw[k];
-                nl += bn[k];
-                if (nl == 0 || nl == n) continue;
-                if (nl > child_cap || n - nl > child_cap) continue;  // would break the level bound
-                const double cost = acc.half_area() * w + right_cost[k + 1];
-                if (cost < best_cost) best_cost = cost, best_axis = ax, best_bin = k;
-            }
-        }
+        const SplitChoice choice = choose_split(scale, n, child_cap, [&](int ax, int k, Box* bb, double* bw, size_t* bn) {
+            *bb = bins[0].bb[ax][k], *bw = bins[0].bw[ax][k], *bn = bins[0].bn[ax][k];
+        });
+        const int best_axis = choice.axis, best_bin = choice.bin;
         size_t mid;
         if (best_axis >= 0) {
             const int ax = best_axis;
@@ -283,8 +330,9 @@ struct Builder {
             for (int k = 1; k < 3; k++)
                 if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
             mid = b + n / 2;
-            std::nth_element(items.begin() + b, items.begin() + mid, items.begin() + e,
-                             [ax](const Item& x, const Item& y) { return x.lo[ax] + x.hi[ax] < y.lo[ax] + y.hi[ax]; });
+            std::nth_element(items.begin() + b, items.begin() + mid, items.begin() + e, [ax](const Item& x, const Item& y) {
+                return median_before(x.lo[ax] + x.hi[ax], x.ref, y.lo[ax] + y.hi[ax], y.ref);
+            });
         }
         const uint32_t me = base;
         for (int seen = levels.load(); level + 1 > seen && !levels.compare_exchange_weak(seen, level + 1);) {
@@ -308,11 +356,7 @@ struct Builder {
         box->grow(r.lo, r.hi);
         return me | ((ref_nocull(rl) || ref_nocull(rr)) ? NOCULL : 0u);
     }
-    static int bin_of(const Item& it, int ax, float lo, double scale) {
-        const double c = 0.5f * it.lo[ax] + 0.5f * it.hi[ax];
-        int k = (int)((c - lo) * scale);
-        return k < 0 ? 0 : (k >= BINS ? BINS - 1 : k);
-    }
+    static int bin_of(const Item& it, int ax, float lo, double scale) { return bin_index(it.lo[ax], it.hi[ax], lo, scale); }
 };
 
 }  // namespace detail
@@ -363,21 +407,36 @@ inline void build_items(std::vector<Item>& items, size_t split, Bvh* out, size_t
 // primitives are dropped (they have no candidates).  An empty tree yields no nodes.  Leaves that hold
 // an unbounded triangle (kind 3) get a tree of their own under the root holder's second slot, so the
 // never-cull mark stays off every path of the main tree.
-inline void build(const rtf::Flat& flat, Bvh* out) {
-    std::vector<detail::Item> items, unbounded;
+// The items of a tree and how they fall into the subtrees under its root holder(s) (detail::build_items).
+struct Items {
+    std::vector<detail::Item> items;
+    size_t split = 0, split2 = 0;  // [0, split) | [split, split2) | [split2, size): third group only in the tight tree
+};
+// (x + 0.0f: a bound of -0 becomes +0.  Box unions are min/max, which return either zero of a tie depending on the
+// order of the operands; with one zero the unions are the same bits in any order -- the two builders visit the items
+// in different orders -- and no comparison of the box tests can tell the zeros apart.)
+inline void make_leaf_items(const rtf::Flat& flat, Items* out) {
+    std::vector<detail::Item>& items = out->items;
+    std::vector<detail::Item> unbounded;
+    items.clear();
     for (const rtf::FlatNode& fn : flat.nodes) {
         const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31;
         if (kind == rtf::KIND_BRANCH || count == 0) continue;
         detail::Item it;
-        it.lo[0] = fn.minx, it.lo[1] = fn.miny, it.lo[2] = fn.minz;
-        it.hi[0] = fn.maxx, it.hi[1] = fn.maxy, it.hi[2] = fn.maxz;
+        it.lo[0] = fn.minx + 0.0f, it.lo[1] = fn.miny + 0.0f, it.lo[2] = fn.minz + 0.0f;
+        it.hi[0] = fn.maxx + 0.0f, it.hi[1] = fn.maxy + 0.0f, it.hi[2] = fn.maxz + 0.0f;
         it.ref = LEAF | (fn.meta & 0x7FFFFFFFu);
         it.weight = (float)count;
         (kind == rtf::KIND_TRI_UNBOUNDED ? unbounded : items).push_back(it);
     }
-    const size_t split = items.size();
+    out->split = items.size();
     items.insert(items.end(), unbounded.begin(), unbounded.end());
-    detail::build_items(items, split, out);
+    out->split2 = items.size();
+}
+inline void build(const rtf::Flat& flat, Bvh* out) {
+    Items it;
+    make_leaf_items(flat, &it);
+    detail::build_items(it.items, it.split, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -474,21 +533,23 @@ inline double near_sphere_pad(const float* rec, const TightInput& in) {
     return NEAR_REL * std::sqrt(d2) + in.pad_tri;
 }
 
-inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, std::vector<int32_t>* tri_slot_leaf,
-                        std::vector<int32_t>* sphere_slot_leaf) {
+inline void make_tight_items(const rtf::Flat& flat, const TightInput& in, Items* out, std::vector<int32_t>* tri_slot_leaf,
+                             std::vector<int32_t>* sphere_slot_leaf) {
     // triangles and spheres get a tree each (the two children of the root holder): the spheres' pad is
     // 64 x the triangles', mixed in they would inflate every inner box above them
-    std::vector<detail::Item> items, sphere_items, near_items;
+    std::vector<detail::Item>& items = out->items;
+    items.clear();
+    std::vector<detail::Item> sphere_items, near_items;
     items.reserve(flat.tri_slot_id.size() + 2 * flat.sphere_slot_id.size());
     tri_slot_leaf->assign(flat.tri_slot_id.size(), 0);
     sphere_slot_leaf->assign(flat.sphere_slot_id.size(), 0);
-    auto down = [](double x) {
+    auto down = [](double x) {  // (+ 0.0f: make_leaf_items)
         float f = (float)x;
-        return (double)f > x ? std::nextafterf(f, -INFINITY) : f;
+        return ((double)f > x ? std::nextafterf(f, -INFINITY) : f) + 0.0f;
     };
     auto up = [](double x) {
         float f = (float)x;
-        return (double)f < x ? std::nextafterf(f, INFINITY) : f;
+        return ((double)f < x ? std::nextafterf(f, INFINITY) : f) + 0.0f;
     };
     auto fill = [&](size_t n0, size_t n1, std::vector<detail::Item>& items, std::vector<detail::Item>& sphere_items,
                     std::vector<detail::Item>& near_items) {
@@ -572,11 +633,16 @@ inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, s
     bool any_sphere = false;
     for (const detail::Item& it : near_items) any_sphere |= ((it.ref >> 29) & 3) == (uint32_t)rtf::KIND_SPHERE;
     if (!any_sphere) near_items.clear();
-    const size_t split = items.size();
+    out->split = items.size();
     items.insert(items.end(), sphere_items.begin(), sphere_items.end());
-    const size_t split2 = items.size();
+    out->split2 = items.size();
     items.insert(items.end(), near_items.begin(), near_items.end());
-    detail::build_items(items, split, out, split2);
+}
+inline void build_tight(const rtf::Flat& flat, const TightInput& in, Bvh* out, std::vector<int32_t>* tri_slot_leaf,
+                        std::vector<int32_t>* sphere_slot_leaf) {
+    Items it;
+    make_tight_items(flat, in, &it, tri_slot_leaf, sphere_slot_leaf);
+    detail::build_items(it.items, it.split, out, it.split2);
     for (int c = 0; c < 3; c++) out->near_lo[c] = in.near_lo[c], out->near_hi[c] = in.near_hi[c];
 }
 
@@ -615,7 +681,8 @@ struct QBvh {
 
 // Quantises a tree built by build_tight.  Empty child slots (inverted boxes) stay inverted (lo index 65535,
 // hi index 0).  Returns false if the tree has no finite root box (then there is nothing to walk).
-inline bool quantize(const Bvh& in, QBvh* out) {
+// the grid of a tree: base and step per axis from the boxes of its root holder (node 0)
+inline bool quantize_grid(const Bvh& in, QBvh* out) {
     out->nodes.clear();
     if (in.nodes.empty()) return false;
     double rlo[3] = {1e300, 1e300, 1e300}, rhi[3] = {-1e300, -1e300, -1e300};
@@ -634,6 +701,10 @@ inline bool quantize(const Bvh& in, QBvh* out) {
         if (!(st > 0)) st = 1e-30f;
         out->step[c] = st;
     }
+    return true;
+}
+inline bool quantize(const Bvh& in, QBvh* out) {
+    if (!quantize_grid(in, out)) return false;
     out->nodes.resize(in.nodes.size());
     out->near_root = in.near_root;
     const size_t n = in.nodes.size();

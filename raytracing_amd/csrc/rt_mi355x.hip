@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "rt_bvh.h"
+#include "rt_gpu_bvh.h"
 #include "rt_gpu_flatten.h"
 #include "rt_kernels.h"
 #include "rt_scene_prep.h"
@@ -80,6 +81,9 @@ struct rt_ctx {
     int coop_shadows = 2;  // RT_OPTION_COOP_SHADOWS: the BVH megakernel regroups the shadow rays of sparse bounces over the
                            // wave: 0 never, 1 always, 2 (default) where it measures faster (tune_begin)
     bool build_tight = true;  // RT_OPTION_TIGHT_TREE (takes effect at the next upload and at once for renders)
+    int gpu_build_min = 20000;    // RT_OPTION_GPU_BUILD_MIN: scenes whose two trees have at least this many items together get
+                                  // them built on the GPU (rt_gpu_bvh.h); -1: never
+    DevBuf gb_bvh, gb_tight, gb_tight_q;  // the device builder's results until upload_prepared has copied them
     int gpu_flatten_min = 65536;  // RT_OPTION_GPU_FLATTEN_MIN: accel arrays of at least this many floats are flattened on
                                   // the GPU (rt_gpu_flatten.h), smaller ones on the host (a launch per tree level costs
                                   // more than the whole host walk there); -1 = never
@@ -436,7 +440,8 @@ void rt_destroy(rt_ctx* ctx) {
     DevBuf* all[] = {&ctx->geom,       &ctx->plane_geom, &ctx->tri_slot_id, &ctx->sphere_slot_id, &ctx->spheres_aos,
                      &ctx->planes_aos, &ctx->tris_aos,   &ctx->lights,      &ctx->ticket,         &ctx->fb_rgb,
                      &ctx->fb_rgba8,   &ctx->fb_pid,     &ctx->fb_fid,      &ctx->fb_stats,
-                     &ctx->tri_slot_leaf, &ctx->sphere_slot_leaf, &ctx->accel_tmp, &ctx->heat[0], &ctx->heat[1], &ctx->order};
+                     &ctx->tri_slot_leaf, &ctx->sphere_slot_leaf, &ctx->accel_tmp, &ctx->heat[0], &ctx->heat[1], &ctx->order,
+                     &ctx->gb_bvh,     &ctx->gb_tight,   &ctx->gb_tight_q};
     for (DevBuf* b : all) release(*b);
     for (DevBuf& b : ctx->ev) release(b);
     delete ctx;
@@ -471,6 +476,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
         case RT_OPTION_BIN_PATHS:
             if (value < 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "first sorted iteration must be >= 0 (0: no binning)");
             ctx->wf_bin_from = value;
+            return RT_OK;
+        case RT_OPTION_GPU_BUILD_MIN:
+            if (value < -1) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "GPU build threshold must be >= -1");
+            ctx->gpu_build_min = value;
             return RT_OK;
         case RT_OPTION_GPU_FLATTEN_MIN:
             if (value < -1) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "GPU flatten threshold must be >= -1");
@@ -508,6 +517,11 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     const bool contained = prep.contained;
     const float* extent = prep.extent;
     const float tight_e = prep.tight_e;
+    // the two derived trees: host vectors, or arrays the device builder left on this GPU (rt_gpu_bvh.h)
+    const rtp::Prepared::DeviceTrees& dev = prep.dev;
+    const size_t n_bvh = dev.on ? dev.n_bvh : bvh.nodes.size(), n_tight = dev.on ? dev.n_tight : tight_q.nodes.size();
+    const int bvh_levels = dev.on ? dev.bvh_levels : bvh.levels;
+    const int tight_levels = n_tight == 0 ? 0 : (dev.on ? dev.tight_levels : tight.levels);
     int rc;
     if ((rc = upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48))) return rc;
     if ((rc = upload(ctx, ctx->planes_aos, planes, (size_t)n_planes * 64))) return rc;
@@ -520,20 +534,20 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     // one contiguous geometry image: nodes | triangle slots | sphere slots | BVH nodes (rt_device.h)
     const size_t tri_off = flat.nodes.size() * 2, sph_off = tri_off + (size_t)n_ts * 3;
     const size_t bvh_off = sph_off + (size_t)n_ss;
-    const size_t geom_f4 = bvh_off + bvh.nodes.size() * 4;
-    const size_t all_f4 = geom_f4 + tight_q.nodes.size() * 2;
+    const size_t geom_f4 = bvh_off + n_bvh * 4;
+    const size_t all_f4 = geom_f4 + n_tight * 2;
     if (all_f4 >= (size_t)INT32_MAX / 2) return fail(ctx, RT_ERR_TOO_LARGE, "geometry image too large");
     if ((rc = ensure(ctx, ctx->geom, all_f4 * 16))) return rc;
     if ((rc = upload(ctx, ctx->tri_slot_leaf, tri_slot_leaf.data(), tri_slot_leaf.size() * 4))) return rc;
     if ((rc = upload(ctx, ctx->sphere_slot_leaf, sphere_slot_leaf.data(), sphere_slot_leaf.size() * 4))) return rc;
-    if (!tight_q.nodes.empty())
-        HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + geom_f4, tight_q.nodes.data(), tight_q.nodes.size() * sizeof(rtb::QNode),
-                               hipMemcpyHostToDevice));
+    if (n_tight)
+        HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + geom_f4, dev.on ? dev.tight_q_nodes : (const void*)tight_q.nodes.data(),
+                               n_tight * sizeof(rtb::QNode), dev.on ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     if (!flat.nodes.empty())
         HIP_TRY(ctx, hipMemcpy(ctx->geom.p, flat.nodes.data(), flat.nodes.size() * 32, hipMemcpyHostToDevice));
-    if (!bvh.nodes.empty())
-        HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + bvh_off, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtb::Node),
-                               hipMemcpyHostToDevice));
+    if (n_bvh)
+        HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + bvh_off, dev.on ? dev.bvh_nodes : (const void*)bvh.nodes.data(),
+                               n_bvh * sizeof(rtb::Node), dev.on ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     if ((rc = ensure(ctx, ctx->plane_geom, (size_t)n_planes * 32))) return rc;
     float4* const tri_geom = (float4*)ctx->geom.p + tri_off;
     float4* const sphere_geom = (float4*)ctx->geom.p + sph_off;
@@ -573,9 +587,9 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     for (int k = 0; k < 3; k++) s.extent[k] = extent[k];
     s.cull_scale = contained ? 0.0078125f : INFINITY;
 
-    s.bvh = bvh.nodes.empty() ? nullptr : (const float4*)ctx->geom.p + bvh_off;
-    s.bvh_levels = std::max(bvh.levels, tight.nodes.empty() ? 0 : tight.levels);
-    s.leaf_levels = bvh.levels;
+    s.bvh = n_bvh == 0 ? nullptr : (const float4*)ctx->geom.p + bvh_off;
+    s.bvh_levels = std::max(bvh_levels, tight_levels);
+    s.leaf_levels = bvh_levels;
     s.bvh_off = (int32_t)bvh_off;
     for (int k = 0; k < 3; k++) s.root_lo[k] = s.root_hi[k] = 0.0f;
     if (!flat.nodes.empty()) {
@@ -595,11 +609,12 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
         const bool usable = !flat.nodes.empty() && std::isfinite(R) && std::isfinite(c1) && c1 + R <= 1e17;
         s.bound_r2 = usable ? std::nextafterf((float)(Rp * Rp), INFINITY) : INFINITY;
     }
-    s.tight = tight_q.nodes.empty() ? nullptr : (const uint4*)((const float4*)ctx->geom.p + geom_f4);
-    for (int k = 0; k < 3; k++) s.tight_base[k] = tight_q.base[k], s.tight_step[k] = tight_q.step[k];
+    s.tight = n_tight == 0 ? nullptr : (const uint4*)((const float4*)ctx->geom.p + geom_f4);
+    for (int k = 0; k < 3; k++)
+        s.tight_base[k] = dev.on ? dev.base[k] : tight_q.base[k], s.tight_step[k] = dev.on ? dev.step[k] : tight_q.step[k];
     s.tight_e = tight_e;
-    s.tight_near_root = tight_q.nodes.empty() ? 0u : tight_q.near_root;
-    for (int k = 0; k < 3; k++) s.near_lo[k] = tight.near_lo[k], s.near_hi[k] = tight.near_hi[k];
+    s.tight_near_root = n_tight == 0 ? 0u : (dev.on ? dev.near_root : tight_q.near_root);
+    for (int k = 0; k < 3; k++) s.near_lo[k] = dev.on ? prep.near_lo[k] : tight.near_lo[k], s.near_hi[k] = dev.on ? prep.near_hi[k] : tight.near_hi[k];
     s.tri_slot_leaf = (const int32_t*)ctx->tri_slot_leaf.p;
     s.sphere_slot_leaf = (const int32_t*)ctx->sphere_slot_leaf.p;
 
@@ -615,18 +630,48 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     // k_render_bvh_lds strides its per-lane stacks by scene.leaf_levels (it walks the re-treed leaves only)
     ctx->lds_bytes = (geom_f4 - tri_off) * 16 + (size_t)LDS_BLOCK * std::max(s.leaf_levels, 1) * 4;
     inf.lds_scene_bytes = (int64_t)ctx->lds_bytes;
-    inf.bvh_nodes = (int64_t)bvh.nodes.size();
-    inf.bvh_levels = bvh.levels;
+    inf.bvh_nodes = (int64_t)n_bvh;
+    inf.bvh_levels = bvh_levels;
     inf.flags = (flat.nested ? RT_SCENE_NESTED : 0) | (contained ? RT_SCENE_CULL : 0);
     inf.unbounded_triangles = prep.unbounded;
-    inf.device_bytes += (int64_t)(bvh.nodes.size() * sizeof(rtb::Node));
-    inf.tight_nodes = (int64_t)tight.nodes.size();
-    inf.tight_levels = tight.nodes.empty() ? 0 : tight.levels;
-    inf.device_bytes += (int64_t)(tight_q.nodes.size() * sizeof(rtb::QNode) + (tri_slot_leaf.size() + sphere_slot_leaf.size()) * 4);
-    ctx->lds_capable = !bvh.nodes.empty() && ctx->lds_bytes <= (size_t)ctx->lds_limit;
+    inf.device_bytes += (int64_t)(n_bvh * sizeof(rtb::Node));
+    inf.tight_nodes = (int64_t)n_tight;
+    inf.tight_levels = tight_levels;
+    inf.device_bytes += (int64_t)(n_tight * sizeof(rtb::QNode) + (tri_slot_leaf.size() + sphere_slot_leaf.size()) * 4);
+    ctx->lds_capable = n_bvh != 0 && ctx->lds_bytes <= (size_t)ctx->lds_limit;
     ctx->has_scene = true;
     ctx->scene_serial++;
     return RT_OK;
+}
+
+// Both derived trees on ctx's GPU (rt_gpu_bvh.h), with prepare's post-conditions (rtp::finish_trees_on_host).  False:
+// the device declined or failed -- nothing of prep was consumed, the host builds.
+static bool build_trees_on_device(rt_ctx* ctx, rtp::Prepared* prep) {
+    rtp::Prepared::DeviceTrees dev;
+    const size_t n_bvh = rtgb::node_count(prep->leaf_items), n_tight = prep->want_tight ? rtgb::node_count(prep->tight_items) : 0;
+    if (ensure(ctx, ctx->gb_bvh, n_bvh * sizeof(rtb::Node)) != RT_OK) return false;
+    if (n_bvh && rtgb::build_on_device(prep->leaf_items, (rtb::Node*)ctx->gb_bvh.p, &dev.bvh_levels, &dev.near_root) != 1) return false;
+    dev.bvh_nodes = ctx->gb_bvh.p, dev.n_bvh = n_bvh;
+    bool tight = n_tight > 0 && n_bvh > 0;  // (no leaf holds a primitive: no tight tree either)
+    if (tight) {
+        if (ensure(ctx, ctx->gb_tight, n_tight * sizeof(rtb::Node)) != RT_OK || ensure(ctx, ctx->gb_tight_q, n_tight * sizeof(rtb::QNode)) != RT_OK)
+            return false;
+        if (rtgb::build_on_device(prep->tight_items, (rtb::Node*)ctx->gb_tight.p, &dev.tight_levels, &dev.near_root) != 1) return false;
+        tight = dev.tight_levels <= rtb::MAX_LEVELS &&
+                rtgb::quantize_on_device((const rtb::Node*)ctx->gb_tight.p, n_tight, (rtb::QNode*)ctx->gb_tight_q.p, dev.base, dev.step);
+        if (hipDeviceSynchronize() != hipSuccess) return false;
+        release(ctx->gb_tight);  // (the fp32 form is only the quantiser's input)
+    }
+    if (tight) {
+        dev.tight_q_nodes = ctx->gb_tight_q.p, dev.n_tight = n_tight;
+    } else {
+        dev.near_root = 0, dev.tight_levels = 0;
+        prep->tri_slot_leaf.clear(), prep->sphere_slot_leaf.clear();
+    }
+    dev.on = true;
+    prep->dev = dev;
+    prep->leaf_items = rtb::Items(), prep->tight_items = rtb::Items();
+    return true;
 }
 
 static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
@@ -639,8 +684,10 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     const int rc = no_throw(ctx, nullptr, [&] {
         return upload_scene(ctx, spheres, n_spheres, planes, n_planes, triangles, n_triangles, accel, accel_len, lights, lights_len);
     });
-    // the copy of the accel array the GPU flatten worked on is not needed once the scene is up (or refused)
-    if (ctx->accel_tmp.p && hipSetDevice(ctx->device) == hipSuccess) release(ctx->accel_tmp);
+    // the copy of the accel array the GPU flatten worked on is not needed once the scene is up (or refused), nor are
+    // the device builder's arrays (upload_prepared has copied them into the geometry image)
+    if ((ctx->accel_tmp.p || ctx->gb_bvh.p || ctx->gb_tight.p || ctx->gb_tight_q.p) && hipSetDevice(ctx->device) == hipSuccess)
+        release(ctx->accel_tmp), release(ctx->gb_bvh), release(ctx->gb_tight), release(ctx->gb_tight_q);
     return rc;
 }
 static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
@@ -669,9 +716,21 @@ static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const v
     std::string err;
     rtp::Options opt;
     opt.build_tight = ctx->build_tight, opt.tight_min_nodes = ctx->tight_min_nodes;
+    // the two derived trees of a large scene are built on the GPU (rt_gpu_bvh.h; bit-identical to the host builder's,
+    // tests/test_gpu_build.py); a multi-GPU context replicates host arrays and builds on the host threads
+    opt.defer_trees = ctx->gpu_build_min >= 0 && !ctx->multi;
     int rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
                           accel_len, opt, &prep, &err, flat_given);
     if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
+    if (opt.defer_trees) {
+        const auto t1 = std::chrono::steady_clock::now();
+        const bool on_device = prep.leaf_items.items.size() + prep.tight_items.items.size() >= (size_t)ctx->gpu_build_min &&
+                               hipSetDevice(ctx->device) == hipSuccess && build_trees_on_device(ctx, &prep);
+        if (!on_device) rtp::finish_trees_on_host(&prep);
+        if (std::getenv("RT_PREP_TIMING"))
+            std::fprintf(stderr, "[rt prepare] %-28s %8.1f ms\n", on_device ? "both trees (SAH) on the GPU" : "both trees (SAH), host",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    }
     if (ctx->multi) return multi_upload(ctx, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
     return upload_prepared(ctx, prep, spheres, n_spheres, planes, n_planes, triangles, n_triangles, lights, lights_len);
 }
@@ -752,6 +811,98 @@ int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, in
         info->unbounded_triangles = prep.unbounded;
     }
     return rc;
+}
+
+int rt_check_gpu_build(rt_ctx* ctx, const void* spheres, int n_spheres, const void* triangles, int n_triangles, const float* accel,
+                       int64_t accel_len, int tight_min_nodes, char* err, size_t err_cap) {
+    if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+    if (accel_len < 0 || n_spheres < 0 || n_triangles < 0 || tight_min_nodes < 0 || (accel_len && !accel) || (n_spheres && !spheres) ||
+        (n_triangles && !triangles))
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "negative size or null array");
+    std::string msg;
+    int result = 1;
+    const int rc = no_throw(ctx, &msg, [&]() -> int {
+        rtp::Prepared prep;
+        rtp::Options opt;
+        opt.tight_min_nodes = tight_min_nodes, opt.defer_trees = true;
+        const int r = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
+                                   accel_len, opt, &prep, &msg);
+        if (r != RT_OK) return r;
+        const rtb::Items leaf = prep.leaf_items, tight = prep.tight_items;  // (the host build permutes its copy)
+        const bool want_tight = prep.want_tight;
+        rtb::Bvh host_tight;
+        {   // the host's tight tree before prepare's own post-conditions may drop it
+            rtb::Items t = tight;
+            if (want_tight) rtb::detail::build_items(t.items, t.split, &host_tight, t.split2);
+        }
+        rtp::finish_trees_on_host(&prep);
+        if (hipSetDevice(ctx->device) != hipSuccess) return RT_ERR_DEVICE;
+        struct Cmp {
+            const char* name;
+            const rtb::Items* items;
+            const rtb::Bvh* host;
+        } const trees[2] = {{"re-treed leaves", &leaf, &prep.bvh}, {"tight tree", &tight, &host_tight}};
+        for (const Cmp& t : trees) {
+            if (t.items->items.empty()) continue;
+            const size_t n_nodes = rtgb::node_count(*t.items);
+            if (n_nodes != t.host->nodes.size()) {
+                msg = std::string(t.name) + ": node counts differ";
+                return RT_ERR_DEVICE;
+            }
+            rtgb::Buffers mem;
+            rtb::Node* d_nodes = mem.get<rtb::Node>(n_nodes);
+            rtb::QNode* d_q = mem.get<rtb::QNode>(n_nodes);
+            if (!d_nodes || !d_q) return RT_ERR_DEVICE;
+            int levels = 0;
+            uint32_t near_root = 0;
+            const int took = rtgb::build_on_device(*t.items, d_nodes, &levels, &near_root);
+            if (took < 0) {
+                msg = std::string(t.name) + ": HIP error in the device build: " + hipGetErrorString(hipGetLastError());
+                return RT_ERR_DEVICE;
+            }
+            if (took == 0) {
+                result = 0;
+                continue;
+            }
+            std::vector<rtb::Node> dev(n_nodes);
+            if (hipMemcpy(dev.data(), d_nodes, n_nodes * sizeof(rtb::Node), hipMemcpyDeviceToHost) != hipSuccess) return RT_ERR_DEVICE;
+            if (levels != t.host->levels || near_root != t.host->near_root) {
+                msg = std::string(t.name) + ": levels / second holder differ (" + std::to_string(levels) + " vs " +
+                      std::to_string(t.host->levels) + ")";
+                return RT_ERR_DEVICE;
+            }
+            for (size_t i = 0; i < n_nodes; i++)
+                if (std::memcmp(&dev[i], &t.host->nodes[i], sizeof(rtb::Node)) != 0) {
+                    const rtb::Node &a = dev[i], &b = t.host->nodes[i];
+                    char line[256];
+                    std::snprintf(line, sizeof line, ": node %zu of %zu differs (device refs %08x %08x, host %08x %08x; lo.x %g %g | %g %g)", i,
+                                  n_nodes, a.ref[0], a.ref[1], b.ref[0], b.ref[1], a.lo[0][0], a.lo[0][1], b.lo[0][0], b.lo[0][1]);
+                    msg = std::string(t.name) + line;
+                    return RT_ERR_DEVICE;
+                }
+            if (t.host == &host_tight && !prep.tight_q.nodes.empty()) {  // the 16-bit grid form
+                float base[3], step[3];
+                if (!rtgb::quantize_on_device(d_nodes, n_nodes, d_q, base, step)) {
+                    msg = "tight tree: the device found no grid";
+                    return RT_ERR_DEVICE;
+                }
+                std::vector<rtb::QNode> q(n_nodes);
+                if (hipMemcpy(q.data(), d_q, n_nodes * sizeof(rtb::QNode), hipMemcpyDeviceToHost) != hipSuccess) return RT_ERR_DEVICE;
+                if (std::memcmp(base, prep.tight_q.base, 12) != 0 || std::memcmp(step, prep.tight_q.step, 12) != 0 ||
+                    std::memcmp(q.data(), prep.tight_q.nodes.data(), n_nodes * sizeof(rtb::QNode)) != 0) {
+                    msg = "tight tree: the 16-bit grid forms differ";
+                    return RT_ERR_DEVICE;
+                }
+            }
+        }
+        return RT_OK;
+    });
+    if (err && err_cap) {
+        std::strncpy(err, msg.c_str(), err_cap - 1);
+        err[err_cap - 1] = 0;
+    }
+    if (rc != RT_OK) return fail(ctx, rc, msg);
+    return result;
 }
 
 int rt_check_gpu_flatten(rt_ctx* ctx, const float* accel, int64_t accel_len, int n_spheres, int n_triangles, char* err,

@@ -22,6 +22,8 @@ namespace rtp {
 struct Options {
     bool build_tight = true;
     int tight_min_nodes = 1000;  // flat node records from which a scene gets the tight tree
+    bool defer_trees = false;    // stop after the items of both trees: the caller builds them (rt_gpu_bvh.h) or calls
+                                 // finish_trees_on_host
 };
 
 struct Prepared {
@@ -36,7 +38,48 @@ struct Prepared {
     float tight_e = 0;            // E_build of the tight tree's pads
     float pad_tri = 0, pad_sphere = 0;
     int64_t unbounded = 0;
+    // what the two trees are built from (consumed by finish_trees_on_host; with Options::defer_trees left to the caller)
+    rtb::Items leaf_items, tight_items;
+    bool want_tight = false;
+    float near_lo[3] = {0, 0, 0}, near_hi[3] = {0, 0, 0};  // rtb::TightInput::near_lo / near_hi of the tight items
+    // Trees the caller built on its GPU instead (rt_gpu_bvh.h): device arrays in the layouts of bvh.nodes and
+    // tight_q.nodes; `bvh`, `tight` and `tight_q` above then stay empty.
+    struct DeviceTrees {
+        bool on = false;
+        const void* bvh_nodes = nullptr;
+        size_t n_bvh = 0;
+        int bvh_levels = 0;
+        const void* tight_q_nodes = nullptr;
+        size_t n_tight = 0;
+        int tight_levels = 0;
+        uint32_t near_root = 0;
+        float base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
+    } dev;
 };
+
+// The SAH builds over Prepared::leaf_items / tight_items on host threads (side by side: both builders fork further
+// below their first levels, neither reads what the other writes), then the 16-bit grid form of the tight tree.
+inline void finish_trees_on_host(Prepared* out) {
+    out->bvh = rtb::Bvh();
+    out->tight = rtb::Bvh();
+    rtb::Crew tight_builder;  // (joined whatever happens below; a failure in either builder is rethrown by finish())
+    if (out->want_tight)
+        tight_builder.start([&] {
+            rtb::detail::build_items(out->tight_items.items, out->tight_items.split, &out->tight, out->tight_items.split2);
+            for (int c = 0; c < 3; c++) out->tight.near_lo[c] = out->near_lo[c], out->tight.near_hi[c] = out->near_hi[c];
+        });
+    if (!out->leaf_items.items.empty()) rtb::detail::build_items(out->leaf_items.items, out->leaf_items.split, &out->bvh);
+    if (out->want_tight) {
+        tight_builder.finish();
+        if (out->bvh.nodes.empty() || out->tight.levels > rtb::MAX_LEVELS) {  // (no leaf holds a primitive / too deep)
+            out->tight = rtb::Bvh();
+            out->tri_slot_leaf.clear(), out->sphere_slot_leaf.clear();
+        }
+    }
+    out->tight_q = rtb::QBvh();
+    if (!out->tight.nodes.empty() && !rtb::quantize(out->tight, &out->tight_q)) out->tight = rtb::Bvh();
+    out->leaf_items = rtb::Items(), out->tight_items = rtb::Items();
+}
 
 // Is a triangle record (TriangleStruct, 96 B: A|_ B|_ C|_ N|_ ...) accepted on a line or plane?  Its three
 // edge tests accept the intersection of three half-planes of the plane through A with the stored normal;
@@ -171,9 +214,11 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
     out->pad_tri = out->tight_e * (1.0f / 16384.0f), out->pad_sphere = out->tight_e * (1.0f / 256.0f);
     const bool want_tight = opt.build_tight && out->contained && flat.nested && (int64_t)flat.nodes.size() >= opt.tight_min_nodes &&
                             max_extent <= 1e6f;
-    rtb::Crew tight_builder;  // (joined whatever happens below; a failure in either builder is rethrown by finish())
+    out->want_tight = want_tight;
+    out->leaf_items = rtb::Items(), out->tight_items = rtb::Items();
+    rtb::Crew tight_items;  // (joined whatever happens below; a failure in either thread is rethrown by finish())
     if (want_tight)
-        tight_builder.start([&] {
+        tight_items.start([&] {
             rtb::TightInput in;
             in.tris = triangles, in.spheres = spheres;
             in.pad_tri = out->pad_tri, in.pad_sphere = out->pad_sphere;
@@ -187,21 +232,15 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
                 const float grow = 1.0f / 32.0f;  // (measured on Soup1M 4K: 1/32 48.0 ms, 1/2 47.8, 1 48.5, 2 50.2)
                 for (int k = 0; k < 3; k++) in.near_lo[k] = rlo[k] - max_extent * grow, in.near_hi[k] = rhi[k] + max_extent * grow;
             }
-            rtb::build_tight(flat, in, &out->tight, &out->tri_slot_leaf, &out->sphere_slot_leaf);
+            for (int k = 0; k < 3; k++) out->near_lo[k] = in.near_lo[k], out->near_hi[k] = in.near_hi[k];
+            rtb::make_tight_items(flat, in, &out->tight_items, &out->tri_slot_leaf, &out->sphere_slot_leaf);
         });
-    if (flat.nested) rtb::build(flat, &out->bvh);
-    lap("re-tree the leaves (SAH)");
-    if (want_tight) {
-        tight_builder.finish();
-        if (out->bvh.nodes.empty() || out->tight.levels > rtb::MAX_LEVELS) {  // (no leaf holds a primitive / too deep)
-            out->tight = rtb::Bvh();
-            out->tri_slot_leaf.clear(), out->sphere_slot_leaf.clear();
-        }
-    }
-    lap("tight tree (SAH), the rest");
-    out->tight_q = rtb::QBvh();
-    if (!out->tight.nodes.empty() && !rtb::quantize(out->tight, &out->tight_q)) out->tight = rtb::Bvh();
-    lap("tight tree -> 16-bit grid");
+    if (flat.nested) rtb::make_leaf_items(flat, &out->leaf_items);
+    tight_items.finish();
+    lap("items of both trees");
+    if (opt.defer_trees) return rtf::FLATTEN_OK;
+    finish_trees_on_host(out);
+    lap("both trees (SAH), 16-bit grid");
     return rtf::FLATTEN_OK;
 }
 

@@ -96,7 +96,7 @@ class RayTracer:
             raise RtError(rc, self._lib.rt_last_error(self._ctx).decode())
 
     OPTION_USE_LDS, OPTION_SUPERTILE, OPTION_TRAVERSAL, OPTION_TIGHT_TREE, OPTION_WAVEFRONT_MIN_NODES = 1, 2, 3, 4, 5
-    OPTION_TIGHT_MIN_NODES, OPTION_COOP_SHADOWS, OPTION_GPU_FLATTEN_MIN, OPTION_FRAME_FEEDBACK, OPTION_BIN_PATHS = 6, 7, 8, 9, 10
+    OPTION_TIGHT_MIN_NODES, OPTION_COOP_SHADOWS, OPTION_GPU_FLATTEN_MIN, OPTION_FRAME_FEEDBACK, OPTION_BIN_PATHS, OPTION_GPU_BUILD_MIN = 6, 7, 8, 9, 10, 11
     TRAVERSAL_AUTO, TRAVERSAL_WAVE, TRAVERSAL_BVH, TRAVERSAL_WAVEFRONT = 0, 1, 2, 3
 
     def set_option(self, option, value):
@@ -227,6 +227,19 @@ class RayTracer:
         err = C.create_string_buffer(512)
         rc = self._lib.rt_check_gpu_flatten(self._ctx, N.ptr(a) if len(a) else None, len(a), int(n_spheres), int(n_triangles),
                                             err, len(err))
+        if rc < 0:
+            raise RtError(rc, err.value.decode() or self._lib.rt_last_error(self._ctx).decode())
+        return rc
+
+    def check_gpu_build(self, scene, tight_min_nodes=0):
+        """rt_check_gpu_build: both trees of the scene built on the host and on the device, compared bit for bit.
+        Returns 1 (identical) or 0 (the device declined a tree); raises RtError with the first difference."""
+        s = np.ascontiguousarray(scene.spheresData, dtype=N.SPHERE_DT)
+        t = np.ascontiguousarray(scene.trianglesData, dtype=N.TRIANGLE_DT)
+        a = np.ascontiguousarray(scene.AccelerationStructureData, dtype=np.float32)
+        err = C.create_string_buffer(512)
+        rc = self._lib.rt_check_gpu_build(self._ctx, N.ptr(s) if len(s) else None, len(s), N.ptr(t) if len(t) else None, len(t),
+                                          N.ptr(a) if len(a) else None, len(a), int(tight_min_nodes), err, len(err))
         if rc < 0:
             raise RtError(rc, err.value.decode() or self._lib.rt_last_error(self._ctx).decode())
         return rc

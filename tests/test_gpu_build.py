@@ -1,0 +1,76 @@
+"""The upload builds its two derived trees -- the re-treed leaves and the tight per-primitive tree -- on the GPU
+(csrc/rt_gpu_bvh.h: large nodes level by level over the whole item array, subtrees of <= 64 items by one wave each).
+rt_check_gpu_build runs the host's recursive builder and the device's on the same items and compares node arrays,
+depths, the second root holder and the 16-bit grid form bit for bit."""
+import numpy as np
+import pytest
+
+from raytracing_amd import _native as N
+from raytracing_amd import host
+from raytracing_amd.host import Scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,params", [("TestScene1", None), ("TeapotScene", None), ("TeapotTable", None),
+                                         ("Soup", [3000, 30, 4]), ("Soup", [20000, 200, 8]), ("Soup", [150000, 1500, 8])])
+def test_device_trees_equal_host_trees(name, params, rt, scene_of):
+    assert rt.check_gpu_build(scene_of(name, params)) == 1
+
+
+def _scene_of_triangles(a, b, c, spheres=None):
+    tri = np.zeros(len(a), N.TRIANGLE_DT)
+    n = np.cross(b - a, c - a)
+    tri["PointA"], tri["PointB"], tri["PointC"] = a, b, c
+    tri["Normal"] = n / np.linalg.norm(n, axis=1, keepdims=True)
+    tri["DiffuseColor"] = 0.5
+    sph = np.zeros(0, N.SPHERE_DT) if spheres is None else spheres
+    accel = host.accel_from_structs(sph, tri)
+    lights = np.array([0, 20, 0, 300, 300, 300], np.float32)
+    cam = host.camera_pack([0, 5, -20], [0, 0, 1], [1, 0, 0], 1.0, 1.6, 0.9, 64, 36)
+    return Scene(sph, np.zeros(0, N.PLANE_DT), tri, accel, lights, cam)
+
+
+def test_coincident_items_in_small_subtrees_take_the_median_split(rt):
+    """Copies of one triangle (coincident centroids: the binned search finds no split) in groups of up to 40, far apart:
+    every group ends up in a subtree that one wave builds, with the host's median split ordered by (key, ref)."""
+    g = np.random.default_rng(11)
+    a, b, c = [], [], []
+    for grp in range(60):
+        o = np.array([grp * 10.0, 0, 0]) + g.uniform(-1, 1, 3)
+        p = [o, o + g.uniform(0.5, 1, 3), o + g.uniform(0.5, 1, 3)]
+        for _ in range(int(g.integers(2, 41))):
+            a.append(p[0]), b.append(p[1]), c.append(p[2])
+    sc = _scene_of_triangles(np.array(a, np.float32), np.array(b, np.float32), np.array(c, np.float32))
+    assert rt.check_gpu_build(sc) == 1
+
+
+def test_a_large_node_of_coincident_items_is_left_to_the_host(rt):
+    """3000 concentric copies of one triangle whose box is centred on the origin (coincident centroids, different
+    boxes -- identical ones make the reference's own R-tree builder throw): the leaves' tree has no split between bins at
+    its root -- the device declines, an upload builds on the host threads and renders as ever."""
+    one = np.array([[-1, -1, -1], [1, -1, 1], [0, 1, 0]], np.float32)
+    scale = (1 + 0.001 * np.arange(3000, dtype=np.float32))[:, None]
+    a, b, c = (one[k] * scale for k in range(3))
+    sc = _scene_of_triangles(a, b, c)
+    assert rt.check_gpu_build(sc) == 0
+    rt.SendPrimitivesToShader(sc)
+    rt.PrepareRenderOpenGL(sc.cameraData)
+    out = rt.RenderGL(1)
+    assert out["primary_id"].shape == (36, 64)
+
+
+def test_negative_zero_bounds(rt):
+    """Box bounds of -0.0 and +0.0 (an OBJ file's "-0.000000"): the builders canonicalise them, so the unions do not
+    depend on the order in which the items are visited."""
+    g = np.random.default_rng(5)
+    n = 5000
+    a = g.uniform(-4, 4, (n, 3)).astype(np.float32)
+    a[::3, 0] = -0.0
+    a[1::3, 1] = 0.0
+    b = a + g.uniform(0.1, 0.5, (n, 3)).astype(np.float32)
+    c = a + g.uniform(0.1, 0.5, (n, 3)).astype(np.float32)
+    b[::3, 0] = -0.0
+    c[1::3, 1] = 0.0
+    c[:, 2] += 0.7          # (no flat boxes: the reference's own R-tree builder throws on leaves of zero-volume pairs)
+    assert rt.check_gpu_build(_scene_of_triangles(a, b, c)) == 1
