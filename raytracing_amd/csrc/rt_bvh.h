@@ -486,34 +486,34 @@ inline void build(const rtf::Flat& flat, Bvh* out) {
 // Shape of a triangle record (TriangleStruct: A|_ B|_ C|_ N|_) as the edge tests see it: L = longest edge,
 // ratio = (area of A B' C' doubled) / L^2 ~ the smallest angle for a sliver.  False if the stored normal is zero
 // or NaN (then the triangle is never hit) -- ratio may still be 0 or NaN for collinear vertices.
-inline bool triangle_shape(const float* rec, double* ratio, double* longest) {
+RT_BVH_HD inline bool triangle_shape(const float* rec, double* ratio, double* longest) {
     const float* n = rec + 12;
-    const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+    const double nn = sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
     if (!(nn == nn) || !(nn > 0)) return false;
     const double e1[3] = {(double)rec[4] - rec[0], (double)rec[5] - rec[1], (double)rec[6] - rec[2]};
     const double e2[3] = {(double)rec[8] - rec[0], (double)rec[9] - rec[1], (double)rec[10] - rec[2]};
     const double e3[3] = {e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2]};
     const double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-    const double area2 = std::fabs(cr[0] * n[0] + cr[1] * n[1] + cr[2] * n[2]) / nn;
-    const double len2 = std::max({e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2],
-                                  e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]});
-    *ratio = area2 / len2, *longest = std::sqrt(len2);
+    const double area2 = fabs(cr[0] * n[0] + cr[1] * n[1] + cr[2] * n[2]) / nn;
+    const double l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2],
+                 l3 = e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2];
+    double len2 = l1;  // (std::max of the three)
+    if (len2 < l2) len2 = l2;
+    if (len2 < l3) len2 = l3;
+    *ratio = area2 / len2, *longest = sqrt(len2);
     return true;
 }
 // How far past a vertex the rounding of the edge tests lets an accepted hit point lie (see the proof above);
 // 0 for a triangle that is never hit, +inf for collinear vertices.
-inline double sliver_reach(const float* rec) {
+RT_BVH_HD inline double sliver_reach(const float* rec) {
     double ratio, longest;
     if (!triangle_shape(rec, &ratio, &longest)) return 0.0;
     if (!(ratio > 0)) return INFINITY;
     return 8.0 * 5.9604644775390625e-8 * longest / ratio;
 }
 
-struct TightInput {
-    const unsigned char* tris = nullptr;     // TriangleStruct records, 96 B: A|_ B|_ C|_ N|_ ...
-    const unsigned char* spheres = nullptr;  // SphereStruct records, 48 B: center, radius
+struct TightPads {  // (the part of TightInput the per-slot box rules need; a kernel argument of rt_gpu_bvh.h)
     float pad_tri = 0, pad_sphere = 0;
-    const std::vector<uint8_t>* tri_unbounded = nullptr;  // per triangle slot: accepted on a line / plane (rtf::meta_nocull)
     // Origins of many rays of a frame -- shadow and bounce rays from hit points on the primitives -- lie inside the
     // scene's root box (grown a little: near_lo..near_hi).  For such an origin |o - c| is bounded per sphere by the
     // distance D from its centre to the farthest corner of that region, so its pad can be NEAR_REL * D (+ pad_tri)
@@ -522,15 +522,50 @@ struct TightInput {
     bool near_on = false;
     float near_lo[3] = {0, 0, 0}, near_hi[3] = {0, 0, 0};
 };
+struct TightInput : TightPads {
+    const unsigned char* tris = nullptr;     // TriangleStruct records, 96 B: A|_ B|_ C|_ N|_ ...
+    const unsigned char* spheres = nullptr;  // SphereStruct records, 48 B: center, radius
+    const std::vector<uint8_t>* tri_unbounded = nullptr;  // per triangle slot: accepted on a line / plane (rtf::meta_nocull)
+};
 constexpr double NEAR_REL = 2.05e-3;  // the sphere bound of the proof above (X_c within 2.0e-3 |o-c| of the sphere), with room
 // pad of a sphere's box in the tree for near origins
-inline double near_sphere_pad(const float* rec, const TightInput& in) {
+RT_BVH_HD inline double near_sphere_pad(const float* rec, const TightPads& in) {
     double d2 = 0;
     for (int c = 0; c < 3; c++) {
-        const double far = std::max(std::fabs((double)rec[c] - in.near_lo[c]), std::fabs((double)in.near_hi[c] - rec[c]));
+        const double a = fabs((double)rec[c] - in.near_lo[c]), b = fabs((double)in.near_hi[c] - rec[c]);
+        const double far = a < b ? b : a;
         d2 += far * far;
     }
-    return NEAR_REL * std::sqrt(d2) + in.pad_tri;
+    return NEAR_REL * sqrt(d2) + in.pad_tri;
+}
+// The boxes of the tight tree's items (the rules of the comment above), shared with the device's item kernels.
+// (+ 0.0f: make_leaf_items)
+RT_BVH_HD inline float round_down(double x) {
+    const float f = (float)x;
+    return ((double)f > x ? nextafterf(f, -INFINITY) : f) + 0.0f;
+}
+RT_BVH_HD inline float round_up(double x) {
+    const float f = (float)x;
+    return ((double)f < x ? nextafterf(f, INFINITY) : f) + 0.0f;
+}
+RT_BVH_HD inline void grown_box(const double* lo, const double* hi, double pad, float* out_lo, float* out_hi) {
+    for (int c = 0; c < 3; c++) out_lo[c] = round_down(lo[c] - pad), out_hi[c] = round_up(hi[c] + pad);
+}
+// bbox(A, B', C'): B', C' = B, C projected along the stored normal onto the plane through A
+RT_BVH_HD inline void projected_triangle_box(const float* r, double* lo, double* hi) {
+    const double n[3] = {r[12], r[13], r[14]};
+    const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    for (int c = 0; c < 3; c++) lo[c] = hi[c] = r[c];
+    for (int v = 1; v < 3; v++) {
+        const double e[3] = {(double)r[4 * v] - r[0], (double)r[4 * v + 1] - r[1], (double)r[4 * v + 2] - r[2]};
+        // projection along N onto the plane through A; a zero or NaN normal never yields a hit
+        const double s = (e[0] * n[0] + e[1] * n[1] + e[2] * n[2]) / nn;
+        const bool project = nn > 0 && s == s;
+        for (int c = 0; c < 3; c++) {
+            const double x = project ? (double)r[4 * v + c] - s * n[c] : (double)r[4 * v + c];
+            lo[c] = x < lo[c] ? x : lo[c], hi[c] = hi[c] < x ? x : hi[c];
+        }
+    }
 }
 
 inline void make_tight_items(const rtf::Flat& flat, const TightInput& in, Items* out, std::vector<int32_t>* tri_slot_leaf,
@@ -543,14 +578,6 @@ inline void make_tight_items(const rtf::Flat& flat, const TightInput& in, Items*
     items.reserve(flat.tri_slot_id.size() + 2 * flat.sphere_slot_id.size());
     tri_slot_leaf->assign(flat.tri_slot_id.size(), 0);
     sphere_slot_leaf->assign(flat.sphere_slot_id.size(), 0);
-    auto down = [](double x) {  // (+ 0.0f: make_leaf_items)
-        float f = (float)x;
-        return ((double)f > x ? std::nextafterf(f, -INFINITY) : f) + 0.0f;
-    };
-    auto up = [](double x) {
-        float f = (float)x;
-        return ((double)f < x ? std::nextafterf(f, INFINITY) : f) + 0.0f;
-    };
     auto fill = [&](size_t n0, size_t n1, std::vector<detail::Item>& items, std::vector<detail::Item>& sphere_items,
                     std::vector<detail::Item>& near_items) {
     for (size_t ni = n0; ni < n1; ni++) {
@@ -570,8 +597,8 @@ inline void make_tight_items(const rtf::Flat& flat, const TightInput& in, Items*
                 // box (the exact rule): that box grown by the triangles' pad, walked without a distance window
                 // (kind 3 = never cull, propagated to the inner refs above).  Kept out of the triangles' tree.
                 (*tri_slot_leaf)[slot] = (int32_t)ni;
-                const float flo[3] = {fn.minx, fn.miny, fn.minz}, fhi[3] = {fn.maxx, fn.maxy, fn.maxz};
-                for (int c = 0; c < 3; c++) it.lo[c] = down((double)flo[c] - in.pad_tri), it.hi[c] = up((double)fhi[c] + in.pad_tri);
+                const double flo[3] = {fn.minx, fn.miny, fn.minz}, fhi[3] = {fn.maxx, fn.maxy, fn.maxz};
+                grown_box(flo, fhi, in.pad_tri, it.lo, it.hi);
                 it.ref = LEAF | ((uint32_t)rtf::KIND_TRI_UNBOUNDED << 29) | (1u << 24) | (uint32_t)slot;
                 sphere_items.push_back(it);
                 if (in.near_on) near_items.push_back(it);  // (reachable from either root holder)
@@ -580,19 +607,7 @@ inline void make_tight_items(const rtf::Flat& flat, const TightInput& in, Items*
             if (kind == rtf::KIND_TRI) {
                 (*tri_slot_leaf)[slot] = (int32_t)ni;
                 const float* r = (const float*)(in.tris + (size_t)flat.tri_slot_id[slot] * 96);
-                const double n[3] = {r[12], r[13], r[14]};
-                const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-                for (int c = 0; c < 3; c++) lo[c] = hi[c] = r[c];
-                for (int v = 1; v < 3; v++) {
-                    const double e[3] = {(double)r[4 * v] - r[0], (double)r[4 * v + 1] - r[1], (double)r[4 * v + 2] - r[2]};
-                    // projection along N onto the plane through A; a zero or NaN normal never yields a hit
-                    const double s = (e[0] * n[0] + e[1] * n[1] + e[2] * n[2]) / nn;
-                    const bool project = nn > 0 && s == s;
-                    for (int c = 0; c < 3; c++) {
-                        const double x = project ? (double)r[4 * v + c] - s * n[c] : (double)r[4 * v + c];
-                        lo[c] = std::min(lo[c], x), hi[c] = std::max(hi[c], x);
-                    }
-                }
+                projected_triangle_box(r, lo, hi);
                 pad = in.pad_tri + sliver_reach(r);  // (bounded: <= max_extent / 512 for every triangle that gets here)
             } else {
                 (*sphere_slot_leaf)[slot] = (int32_t)ni;
@@ -600,13 +615,13 @@ inline void make_tight_items(const rtf::Flat& flat, const TightInput& in, Items*
                 for (int c = 0; c < 3; c++) lo[c] = (double)r[c] - r[3], hi[c] = (double)r[c] + r[3];
                 pad = in.pad_sphere;
                 if (in.near_on) {
-                    const double np = std::min(near_sphere_pad(r, in), (double)in.pad_sphere);
+                    const double nsp = near_sphere_pad(r, in), np = (double)in.pad_sphere < nsp ? (double)in.pad_sphere : nsp;
                     detail::Item nit = it;
-                    for (int c = 0; c < 3; c++) nit.lo[c] = down(lo[c] - np), nit.hi[c] = up(hi[c] + np);
+                    grown_box(lo, hi, np, nit.lo, nit.hi);
                     near_items.push_back(nit);
                 }
             }
-            for (int c = 0; c < 3; c++) it.lo[c] = down(lo[c] - pad), it.hi[c] = up(hi[c] + pad);
+            grown_box(lo, hi, pad, it.lo, it.hi);
             (kind == rtf::KIND_TRI ? items : sphere_items).push_back(it);
         }
     }

@@ -464,110 +464,243 @@ __global__ __launch_bounds__(256) void k_quantize(const Node* in, rtb::QNode* ou
 }
 
 // ------------------------------------------------------------------------------------------
-// Host side.  Device memory of one build; freed when the object goes (the trees themselves are copied out by the caller).
+// The items of both trees, made on the device from the flattened reference tree and the uploaded records with the
+// host's own box rules (rt_bvh.h make_leaf_items / make_tight_items: binary64 without contraction, IEEE / and sqrt).
+// Places are handed out by atomics -- the builds do not depend on the order of the items.
 // ------------------------------------------------------------------------------------------
-struct Buffers {
-    void* p[16] = {};
-    int used = 0;
-    ~Buffers() {
-        for (int i = 0; i < used; i++) (void)hipFree(p[i]);
+// place of this lane's `count` items among those of the wave's lanes, in a group whose fill count is *counter
+__device__ __forceinline__ uint32_t wave_places(uint32_t* counter, uint32_t count) {
+    uint32_t incl = count;
+    const int lane = (int)(threadIdx.x & 63);
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += up;
     }
-    template <class T>
-    T* get(size_t count) {
-        void* q = nullptr;
-        if (used >= 16 || hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
-        p[used++] = q;
-        return (T*)q;
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(counter, total);
+    base = (uint32_t)__shfl((int)base, 63, 64);
+    return base + incl - count;
+}
+
+__global__ __launch_bounds__(256) void k_leaf_items(const rtf::FlatNode* nodes, uint32_t n_nodes, Item* out, uint32_t split, uint32_t* counters) {
+    const uint32_t ni = blockIdx.x * 256 + threadIdx.x;
+    rtf::FlatNode fn{};
+    if (ni < n_nodes) fn = nodes[ni];
+    const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31;
+    const bool valid = ni < n_nodes && kind != rtf::KIND_BRANCH && count != 0;
+    const bool unb = kind == rtf::KIND_TRI_UNBOUNDED;
+    const uint32_t p0 = wave_places(counters + 0, valid && !unb ? 1u : 0u), p1 = wave_places(counters + 1, valid && unb ? 1u : 0u);
+    if (!valid) return;
+    Item it;
+    it.lo[0] = fn.minx + 0.0f, it.lo[1] = fn.miny + 0.0f, it.lo[2] = fn.minz + 0.0f;
+    it.hi[0] = fn.maxx + 0.0f, it.hi[1] = fn.maxy + 0.0f, it.hi[2] = fn.maxz + 0.0f;
+    it.ref = rtb::LEAF | (fn.meta & 0x7FFFFFFFu);
+    it.weight = (float)count;
+    out[unb ? split + p1 : p0] = it;
+}
+
+// groups: [0, split) triangles | [split, split2) spheres + unbounded triangles | [split2, ..) the same for near origins
+__global__ __launch_bounds__(256) void k_tight_items(const rtf::FlatNode* nodes, uint32_t n_nodes, const unsigned char* tris,
+                                                     const unsigned char* spheres, const int32_t* tri_slot_id, const int32_t* sphere_slot_id,
+                                                     const uint8_t* tri_unbounded, rtb::TightPads pads, bool near_group, Item* out,
+                                                     uint32_t split, uint32_t split2, uint32_t* counters, int32_t* tri_slot_leaf,
+                                                     int32_t* sphere_slot_leaf) {
+    const uint32_t ni = blockIdx.x * 256 + threadIdx.x;
+    rtf::FlatNode fn{};
+    if (ni < n_nodes) fn = nodes[ni];
+    const int count = ni < n_nodes ? (int)((fn.meta >> 24) & 31) : 0, first = (int)(fn.meta & 0xFFFFFF);
+    int kind = (fn.meta >> 29) & 3;
+    const bool leaf = ni < n_nodes && kind != rtf::KIND_BRANCH;
+    if (kind == rtf::KIND_TRI_UNBOUNDED) kind = rtf::KIND_TRI;  // decided per slot
+    uint32_t c0 = 0, c1 = 0;
+    if (leaf)
+        for (int k = 0; k < count; k++) {
+            if (kind == rtf::KIND_TRI && !tri_unbounded[first + k])
+                c0++;
+            else
+                c1++;
+        }
+    uint32_t p0 = wave_places(counters + 0, c0), p1 = wave_places(counters + 1, c1);
+    if (!leaf) return;
+    for (int k = 0; k < count; k++) {
+        const int slot = first + k;
+        Item it;
+        it.weight = 1.0f;
+        it.ref = rtb::LEAF | ((uint32_t)kind << 29) | (1u << 24) | (uint32_t)slot;
+        double lo[3], hi[3];
+        if (kind == rtf::KIND_TRI) {
+            tri_slot_leaf[slot] = (int32_t)ni;
+            if (tri_unbounded[slot]) {  // its reference leaf box grown by the triangles' pad, never culled
+                const double flo[3] = {fn.minx, fn.miny, fn.minz}, fhi[3] = {fn.maxx, fn.maxy, fn.maxz};
+                rtb::grown_box(flo, fhi, pads.pad_tri, it.lo, it.hi);
+                it.ref = rtb::LEAF | ((uint32_t)rtf::KIND_TRI_UNBOUNDED << 29) | (1u << 24) | (uint32_t)slot;
+                out[split + p1] = it;
+                if (near_group) out[split2 + p1] = it;
+                p1++;
+                continue;
+            }
+            const float* r = (const float*)(tris + (size_t)tri_slot_id[slot] * 96);
+            rtb::projected_triangle_box(r, lo, hi);
+            rtb::grown_box(lo, hi, pads.pad_tri + rtb::sliver_reach(r), it.lo, it.hi);
+            out[p0++] = it;
+        } else {
+            sphere_slot_leaf[slot] = (int32_t)ni;
+            const float* r = (const float*)(spheres + (size_t)sphere_slot_id[slot] * 48);
+            for (int c = 0; c < 3; c++) lo[c] = (double)r[c] - r[3], hi[c] = (double)r[c] + r[3];
+            if (near_group) {
+                const double nsp = rtb::near_sphere_pad(r, pads), np = (double)pads.pad_sphere < nsp ? (double)pads.pad_sphere : nsp;
+                Item nit = it;
+                rtb::grown_box(lo, hi, np, nit.lo, nit.hi);
+                out[split2 + p1] = nit;
+            }
+            rtb::grown_box(lo, hi, pads.pad_sphere, it.lo, it.hi);
+            out[split + p1] = it;
+            p1++;
+        }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side.  One build = one arena of device memory, freed when the object goes; the caller fills items() -- a copy
+// of host items, or the kernels above -- and runs the build into its own node array.
+// ------------------------------------------------------------------------------------------
+inline size_t node_count(size_t n, size_t split, size_t split2) {
+    if (n == 0) return 0;
+    const size_t bounds[4] = {0, split, split2, n};
+    size_t at = 1;
+    for (int h = 0; h < 3; h++) {
+        const size_t m = bounds[h + 1] - bounds[h];
+        at += m ? m - 1 : 0;
+    }
+    return at + (split2 < n ? 1 : 0);
+}
+inline size_t node_count(const rtb::Items& src) { return node_count(src.items.size(), src.split, src.split2); }
+
+class Build {
+public:
+    ~Build() {
+        if (arena_) (void)hipFree(arena_);
+    }
+    bool alloc(size_t n_items) {
+        n_ = n_items;
+        cap_big_ = n_ / (SMALL_MAX + 1) + 8, cap_chunks_ = n_ / CHUNK + cap_big_ + 8, cap_small_ = n_ / 2 + 8;
+        size_t at = 0;
+        auto take = [&](size_t bytes) {
+            const size_t here = at;
+            at += (bytes + 255) & ~(size_t)255;
+            return here;
+        };
+        const size_t o_items[2] = {take(n_ * sizeof(Item)), take(n_ * sizeof(Item))};
+        const size_t o_big[2] = {take(cap_big_ * sizeof(BigNode)), take(cap_big_ * sizeof(BigNode))};
+        const size_t o_chunks[2] = {take(cap_chunks_ * sizeof(Chunk)), take(cap_chunks_ * sizeof(Chunk))};
+        const size_t o_bins = take(cap_big_ * 3 * BINS * BIN_WORDS * 4), o_small = take(cap_small_ * sizeof(SmallWork));
+        const size_t o_state = take(sizeof(State)), o_counters = take(16);
+        if (hipMalloc(&arena_, at) != hipSuccess) {
+            arena_ = nullptr;
+            return false;
+        }
+        unsigned char* const p = (unsigned char*)arena_;
+        for (int k = 0; k < 2; k++)
+            d_items_[k] = (Item*)(p + o_items[k]), d_big_[k] = (BigNode*)(p + o_big[k]), d_chunks_[k] = (Chunk*)(p + o_chunks[k]);
+        d_bins_ = (uint32_t*)(p + o_bins), d_small_ = (SmallWork*)(p + o_small), d_state_ = (State*)(p + o_state);
+        d_counters_ = (uint32_t*)(p + o_counters);
+        return true;
+    }
+    Item* items() { return d_items_[0]; }
+    uint32_t* counters() { return d_counters_; }  // four words for the item kernels' fill counts (the caller clears them)
+
+    // Builds the tree over items()[0, n): rtb::detail::build_items's node layout into d_out[0, node_count) on the current
+    // device, stream 0.  Returns 1 (built; *levels = rtb::Bvh::levels, *near_root = rtb::Bvh::near_root), 0 (declined: a
+    // large node of coincident centroids -- the host builds), -1 (HIP error).
+    int run(size_t split, size_t split2, Node* d_out, int* levels, uint32_t* near_root) {
+        const size_t n = n_;
+        *levels = 0, *near_root = 0;
+        if (n == 0) return 1;
+        if (n >= 0x1FFFFFFFull) return 0;
+        auto ok = [](hipError_t e) { return e == hipSuccess; };
+        const size_t bounds[4] = {0, split, split2, n};
+        HolderArgs ha{};
+        size_t at = 1;
+        for (int h = 0; h < 3; h++) {
+            ha.n[h] = (uint32_t)(bounds[h + 1] - bounds[h]);
+            ha.base[h] = (uint32_t)at, at += ha.n[h] ? ha.n[h] - 1 : 0;
+            if (ha.n[h] == 1 && !ok(hipMemcpy(&ha.single[h], d_items_[0] + bounds[h], sizeof(Item), hipMemcpyDeviceToHost))) return -1;
+        }
+        ha.near_holder = split2 < n ? (uint32_t)at : 0u;
+        *near_root = ha.near_holder;
+        // the group roots: large ones open the first level, small ones go to k_small as they are
+        std::vector<BigNode> big0;
+        std::vector<Chunk> chunks0;
+        std::vector<SmallWork> small0;
+        for (int h = 0; h < 3; h++) {
+            const uint32_t b = (uint32_t)bounds[h], e = (uint32_t)bounds[h + 1];
+            if (ha.n[h] < 2) continue;
+            if (ha.n[h] <= (uint32_t)SMALL_MAX) {
+                small0.push_back(SmallWork{b, e, ha.base[h], 1u, 0u});
+                continue;
+            }
+            BigNode nd{};
+            nd.b = b, nd.e = e, nd.base = ha.base[h];
+            for (int k = 0; k < 3; k++) nd.cb_lo[k] = 0xFFFFFFFFu, nd.cb_hi[k] = 0u;
+            for (uint32_t c = b; c < e; c += CHUNK) chunks0.push_back(Chunk{(uint32_t)big0.size(), c, std::min<uint32_t>(CHUNK, e - c)});
+            big0.push_back(nd);
+        }
+        State state{};
+        state.n_small = (uint32_t)small0.size();
+        state.levels = 1;  // the holder
+        if (!big0.empty() && (!ok(hipMemcpy(d_big_[0], big0.data(), big0.size() * sizeof(BigNode), hipMemcpyHostToDevice)) ||
+                              !ok(hipMemcpy(d_chunks_[0], chunks0.data(), chunks0.size() * sizeof(Chunk), hipMemcpyHostToDevice))))
+            return -1;
+        if (!small0.empty() && !ok(hipMemcpy(d_small_, small0.data(), small0.size() * sizeof(SmallWork), hipMemcpyHostToDevice))) return -1;
+        if (!ok(hipMemcpy(d_state_, &state, sizeof state, hipMemcpyHostToDevice))) return -1;
+        uint32_t n_big = (uint32_t)big0.size(), n_chunks = (uint32_t)chunks0.size();
+        int cur = 0;
+        for (int level = 1; n_big > 0; level++) {
+            if (level > rtb::MAX_LEVELS) return 0;
+            hipLaunchKernelGGL(k_bounds, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items_[cur], d_chunks_[cur], d_big_[cur]);
+            hipLaunchKernelGGL(k_scale, dim3(n_big), dim3(256), 0, 0, d_big_[cur], d_bins_);
+            hipLaunchKernelGGL(k_bin, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items_[cur], d_chunks_[cur], d_big_[cur], d_bins_);
+            hipLaunchKernelGGL(k_split, dim3((n_big + 63) / 64), dim3(64), 0, 0, d_big_[cur], n_big, d_bins_, level, d_out, d_big_[cur ^ 1],
+                               d_chunks_[cur ^ 1], d_small_, (uint32_t)(cur ^ 1), d_state_);
+            hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items_[cur], d_items_[cur ^ 1], d_chunks_[cur], d_big_[cur],
+                               d_out);
+            if (!ok(hipMemcpy(&state, d_state_, sizeof state, hipMemcpyDeviceToHost))) return -1;
+            if (state.declined) return 0;
+            n_big = state.n_big_next, n_chunks = state.n_chunks_next;
+            if (n_big > cap_big_ || n_chunks > cap_chunks_ || state.n_small > cap_small_) return -1;  // (cannot happen: see the caps)
+            state.n_big_next = state.n_chunks_next = 0;
+            if (!ok(hipMemcpy(d_state_, &state, sizeof state, hipMemcpyHostToDevice))) return -1;
+            cur ^= 1;
+        }
+        if (state.n_small)
+            hipLaunchKernelGGL(k_small, dim3(state.n_small), dim3(64), 0, 0, d_items_[0], d_items_[1], d_small_, d_out, d_state_);
+        hipLaunchKernelGGL(k_holder, dim3(1), dim3(1), 0, 0, d_out, ha);
+        if (!ok(hipGetLastError()) || !ok(hipMemcpy(&state, d_state_, sizeof state, hipMemcpyDeviceToHost))) return -1;
+        *levels = state.levels;
+        return 1;
+    }
+
+private:
+    void* arena_ = nullptr;
+    size_t n_ = 0, cap_big_ = 0, cap_chunks_ = 0, cap_small_ = 0;
+    Item* d_items_[2] = {nullptr, nullptr};
+    BigNode* d_big_[2] = {nullptr, nullptr};
+    Chunk* d_chunks_[2] = {nullptr, nullptr};
+    uint32_t* d_bins_ = nullptr;
+    SmallWork* d_small_ = nullptr;
+    State* d_state_ = nullptr;
+    uint32_t* d_counters_ = nullptr;
 };
 
-// Builds the tree of `src` (rtb::detail::build_items's node layout) into d_out[0, node_count(src)) on the current device,
-// stream 0.  Returns 1 (built; *levels = rtb::Bvh::levels, *near_root = rtb::Bvh::near_root), 0 (declined: a large
-// node of coincident centroids, or no memory -- the host builds), -1 (HIP error).
-inline size_t node_count(const rtb::Items& src) {
-    if (src.items.empty()) return 0;
-    const size_t bounds[4] = {0, src.split, src.split2, src.items.size()};
-    size_t at = 1;
-    for (int h = 0; h < 3; h++) {
-        const size_t n = bounds[h + 1] - bounds[h];
-        at += n ? n - 1 : 0;
-    }
-    return at + (src.split2 < src.items.size() ? 1 : 0);
-}
+// a tree over host items (the self-check's second route; an upload makes its items on the device)
 inline int build_on_device(const rtb::Items& src, Node* d_out, int* levels, uint32_t* near_root) {
-    const size_t n = src.items.size();
+    Build b;
     *levels = 0, *near_root = 0;
-    if (n == 0) return 1;
-    if (n >= 0x1FFFFFFFull) return 0;
-    const size_t bounds[4] = {0, src.split, src.split2, n};
-    HolderArgs ha{};
-    size_t at = 1;
-    for (int h = 0; h < 3; h++) {
-        ha.n[h] = (uint32_t)(bounds[h + 1] - bounds[h]);
-        ha.base[h] = (uint32_t)at, at += ha.n[h] ? ha.n[h] - 1 : 0;
-        if (ha.n[h] == 1) ha.single[h] = src.items[bounds[h]];
-    }
-    ha.near_holder = src.split2 < n ? (uint32_t)at : 0u;
-    *near_root = ha.near_holder;
-    const size_t cap_big = n / (SMALL_MAX + 1) + 8, cap_chunks = n / CHUNK + cap_big + 8, cap_small = n / 2 + 8;
-    Buffers mem;
-    Item* d_items[2] = {mem.get<Item>(n), mem.get<Item>(n)};
-    BigNode* d_big[2] = {mem.get<BigNode>(cap_big), mem.get<BigNode>(cap_big)};
-    Chunk* d_chunks[2] = {mem.get<Chunk>(cap_chunks), mem.get<Chunk>(cap_chunks)};
-    uint32_t* d_bins = mem.get<uint32_t>(cap_big * 3 * BINS * BIN_WORDS);
-    SmallWork* d_small = mem.get<SmallWork>(cap_small);
-    State* d_state = mem.get<State>(1);
-    if (!d_items[0] || !d_items[1] || !d_big[0] || !d_big[1] || !d_chunks[0] || !d_chunks[1] || !d_bins || !d_small || !d_state) return 0;
-    if (hipMemcpy(d_items[0], src.items.data(), n * sizeof(Item), hipMemcpyHostToDevice) != hipSuccess) return -1;
-    // the group roots: large ones open the first level, small ones go to k_small as they are
-    std::vector<BigNode> big0;
-    std::vector<Chunk> chunks0;
-    std::vector<SmallWork> small0;
-    for (int h = 0; h < 3; h++) {
-        const uint32_t b = (uint32_t)bounds[h], e = (uint32_t)bounds[h + 1];
-        if (ha.n[h] < 2) continue;
-        if (ha.n[h] <= (uint32_t)SMALL_MAX) {
-            small0.push_back(SmallWork{b, e, ha.base[h], 1u, 0u});
-            continue;
-        }
-        BigNode nd{};
-        nd.b = b, nd.e = e, nd.base = ha.base[h];
-        for (int k = 0; k < 3; k++) nd.cb_lo[k] = 0xFFFFFFFFu, nd.cb_hi[k] = 0u;
-        for (uint32_t c = b; c < e; c += CHUNK) chunks0.push_back(Chunk{(uint32_t)big0.size(), c, std::min<uint32_t>(CHUNK, e - c)});
-        big0.push_back(nd);
-    }
-    State state{};
-    state.n_small = (uint32_t)small0.size();
-    state.levels = 1;  // the holder
-    auto ok = [](hipError_t e) { return e == hipSuccess; };
-    if (!big0.empty() && (!ok(hipMemcpy(d_big[0], big0.data(), big0.size() * sizeof(BigNode), hipMemcpyHostToDevice)) ||
-                          !ok(hipMemcpy(d_chunks[0], chunks0.data(), chunks0.size() * sizeof(Chunk), hipMemcpyHostToDevice))))
-        return -1;
-    if (!small0.empty() && !ok(hipMemcpy(d_small, small0.data(), small0.size() * sizeof(SmallWork), hipMemcpyHostToDevice))) return -1;
-    if (!ok(hipMemcpy(d_state, &state, sizeof state, hipMemcpyHostToDevice))) return -1;
-    uint32_t n_big = (uint32_t)big0.size(), n_chunks = (uint32_t)chunks0.size();
-    int cur = 0;
-    for (int level = 1; n_big > 0; level++) {
-        if (level > rtb::MAX_LEVELS) return 0;
-        hipLaunchKernelGGL(k_bounds, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items[cur], d_chunks[cur], d_big[cur]);
-        hipLaunchKernelGGL(k_scale, dim3(n_big), dim3(256), 0, 0, d_big[cur], d_bins);
-        hipLaunchKernelGGL(k_bin, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items[cur], d_chunks[cur], d_big[cur], d_bins);
-        hipLaunchKernelGGL(k_split, dim3((n_big + 63) / 64), dim3(64), 0, 0, d_big[cur], n_big, d_bins, level, d_out, d_big[cur ^ 1],
-                           d_chunks[cur ^ 1], d_small, (uint32_t)(cur ^ 1), d_state);
-        hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items[cur], d_items[cur ^ 1], d_chunks[cur], d_big[cur], d_out);
-        if (!ok(hipMemcpy(&state, d_state, sizeof state, hipMemcpyDeviceToHost))) return -1;
-        if (state.declined) return 0;
-        n_big = state.n_big_next, n_chunks = state.n_chunks_next;
-        if (n_big > cap_big || n_chunks > cap_chunks || state.n_small > cap_small) return -1;  // (cannot happen: see the caps)
-        state.n_big_next = state.n_chunks_next = 0;
-        if (!ok(hipMemcpy(d_state, &state, sizeof state, hipMemcpyHostToDevice))) return -1;
-        cur ^= 1;
-    }
-    if (state.n_small) hipLaunchKernelGGL(k_small, dim3(state.n_small), dim3(64), 0, 0, d_items[0], d_items[1], d_small, d_out, d_state);
-    hipLaunchKernelGGL(k_holder, dim3(1), dim3(1), 0, 0, d_out, ha);
-    if (!ok(hipGetLastError()) || !ok(hipMemcpy(&state, d_state, sizeof state, hipMemcpyDeviceToHost))) return -1;
-    *levels = state.levels;
-    return 1;
+    if (src.items.empty()) return 1;
+    if (!b.alloc(src.items.size())) return 0;
+    if (hipMemcpy(b.items(), src.items.data(), src.items.size() * sizeof(Item), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    return b.run(src.split, src.split2, d_out, levels, near_root);
 }
 
 // rtb::quantize's grid from the root holder of a tree on the device; false: no finite root box

@@ -84,6 +84,7 @@ struct rt_ctx {
     int gpu_build_min = 20000;    // RT_OPTION_GPU_BUILD_MIN: scenes whose two trees have at least this many items together get
                                   // them built on the GPU (rt_gpu_bvh.h); -1: never
     DevBuf gb_bvh, gb_tight, gb_tight_q;  // the device builder's results until upload_prepared has copied them
+    DevBuf gb_flat, gb_unb;               // ... and two of its inputs: the flattened nodes, the unbounded-triangle flags
     int gpu_flatten_min = 65536;  // RT_OPTION_GPU_FLATTEN_MIN: accel arrays of at least this many floats are flattened on
                                   // the GPU (rt_gpu_flatten.h), smaller ones on the host (a launch per tree level costs
                                   // more than the whole host walk there); -1 = never
@@ -441,7 +442,7 @@ void rt_destroy(rt_ctx* ctx) {
                      &ctx->planes_aos, &ctx->tris_aos,   &ctx->lights,      &ctx->ticket,         &ctx->fb_rgb,
                      &ctx->fb_rgba8,   &ctx->fb_pid,     &ctx->fb_fid,      &ctx->fb_stats,
                      &ctx->tri_slot_leaf, &ctx->sphere_slot_leaf, &ctx->accel_tmp, &ctx->heat[0], &ctx->heat[1], &ctx->order,
-                     &ctx->gb_bvh,     &ctx->gb_tight,   &ctx->gb_tight_q};
+                     &ctx->gb_bvh,     &ctx->gb_tight,   &ctx->gb_tight_q,  &ctx->gb_flat,        &ctx->gb_unb};
     for (DevBuf* b : all) release(*b);
     for (DevBuf& b : ctx->ev) release(b);
     delete ctx;
@@ -523,13 +524,15 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     const int bvh_levels = dev.on ? dev.bvh_levels : bvh.levels;
     const int tight_levels = n_tight == 0 ? 0 : (dev.on ? dev.tight_levels : tight.levels);
     int rc;
-    if ((rc = upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48))) return rc;
+    const bool records_there = dev.on && dev.slot_leaf_on_device;  // (the tight tree's item kernel read them: build_trees_on_device)
+    if (!records_there) {
+        if ((rc = upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48))) return rc;
+        if ((rc = upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96))) return rc;
+        if ((rc = upload(ctx, ctx->tri_slot_id, flat.tri_slot_id.data(), flat.tri_slot_id.size() * 4))) return rc;
+        if ((rc = upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), flat.sphere_slot_id.size() * 4))) return rc;
+    }
     if ((rc = upload(ctx, ctx->planes_aos, planes, (size_t)n_planes * 64))) return rc;
-    if ((rc = upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96))) return rc;
     if ((rc = upload(ctx, ctx->lights, lights, (size_t)lights_len * 4))) return rc;
-    if ((rc = upload(ctx, ctx->tri_slot_id, flat.tri_slot_id.data(), flat.tri_slot_id.size() * 4))) return rc;
-    if ((rc = upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), flat.sphere_slot_id.size() * 4)))
-        return rc;
     const int n_ts = (int)flat.tri_slot_id.size(), n_ss = (int)flat.sphere_slot_id.size();
     // one contiguous geometry image: nodes | triangle slots | sphere slots | BVH nodes (rt_device.h)
     const size_t tri_off = flat.nodes.size() * 2, sph_off = tri_off + (size_t)n_ts * 3;
@@ -538,13 +541,16 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     const size_t all_f4 = geom_f4 + n_tight * 2;
     if (all_f4 >= (size_t)INT32_MAX / 2) return fail(ctx, RT_ERR_TOO_LARGE, "geometry image too large");
     if ((rc = ensure(ctx, ctx->geom, all_f4 * 16))) return rc;
-    if ((rc = upload(ctx, ctx->tri_slot_leaf, tri_slot_leaf.data(), tri_slot_leaf.size() * 4))) return rc;
-    if ((rc = upload(ctx, ctx->sphere_slot_leaf, sphere_slot_leaf.data(), sphere_slot_leaf.size() * 4))) return rc;
+    if (!records_there) {
+        if ((rc = upload(ctx, ctx->tri_slot_leaf, tri_slot_leaf.data(), tri_slot_leaf.size() * 4))) return rc;
+        if ((rc = upload(ctx, ctx->sphere_slot_leaf, sphere_slot_leaf.data(), sphere_slot_leaf.size() * 4))) return rc;
+    }
     if (n_tight)
         HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + geom_f4, dev.on ? dev.tight_q_nodes : (const void*)tight_q.nodes.data(),
                                n_tight * sizeof(rtb::QNode), dev.on ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     if (!flat.nodes.empty())
-        HIP_TRY(ctx, hipMemcpy(ctx->geom.p, flat.nodes.data(), flat.nodes.size() * 32, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->geom.p, dev.on ? dev.flat_nodes : (const void*)flat.nodes.data(), flat.nodes.size() * 32,
+                               dev.on ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     if (n_bvh)
         HIP_TRY(ctx, hipMemcpy((float4*)ctx->geom.p + bvh_off, dev.on ? dev.bvh_nodes : (const void*)bvh.nodes.data(),
                                n_bvh * sizeof(rtb::Node), dev.on ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
@@ -637,40 +643,80 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     inf.device_bytes += (int64_t)(n_bvh * sizeof(rtb::Node));
     inf.tight_nodes = (int64_t)n_tight;
     inf.tight_levels = tight_levels;
-    inf.device_bytes += (int64_t)(n_tight * sizeof(rtb::QNode) + (tri_slot_leaf.size() + sphere_slot_leaf.size()) * 4);
+    inf.device_bytes += (int64_t)(n_tight * sizeof(rtb::QNode) +
+                                  (records_there ? (size_t)n_ts + (size_t)n_ss : tri_slot_leaf.size() + sphere_slot_leaf.size()) * 4);
     ctx->lds_capable = n_bvh != 0 && ctx->lds_bytes <= (size_t)ctx->lds_limit;
     ctx->has_scene = true;
     ctx->scene_serial++;
     return RT_OK;
 }
 
-// Both derived trees on ctx's GPU (rt_gpu_bvh.h), with prepare's post-conditions (rtp::finish_trees_on_host).  False:
-// the device declined or failed -- nothing of prep was consumed, the host builds.
-static bool build_trees_on_device(rt_ctx* ctx, rtp::Prepared* prep) {
+// Both derived trees on ctx's GPU (rt_gpu_bvh.h): items made by kernels from the flattened nodes and the caller's
+// records, the SAH builds, the 16-bit grid form -- with prepare's post-conditions (rtp::finish_trees_on_host).
+// prep: as rtp::prepare leaves it with Options::defer_trees.  False: too small for min_items, or the device declined
+// or failed -- the host makes the items and builds.  keep_fp32: leave the tight tree's fp32 nodes in ctx->gb_tight
+// (the self-check compares them).
+static bool build_trees_on_device(rt_ctx* ctx, rtp::Prepared* prep, const void* spheres, int n_spheres, const void* triangles,
+                                  int n_triangles, int64_t min_items, bool keep_fp32 = false) {
+    const rtf::Flat& flat = prep->flat;
+    const size_t n_nodes = flat.nodes.size(), n_ts = flat.tri_slot_id.size(), n_ss = flat.sphere_slot_id.size();
+    // how many items each group of each tree gets (rt_bvh.h make_leaf_items / make_tight_items)
+    size_t leaf0 = 0, leaf1 = 0;
+    if (flat.nested)
+        for (const rtf::FlatNode& fn : flat.nodes) {
+            const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31;
+            if (kind == rtf::KIND_BRANCH || count == 0) continue;
+            (kind == rtf::KIND_TRI_UNBOUNDED ? leaf1 : leaf0)++;
+        }
+    const size_t leaf_n = leaf0 + leaf1;
+    const bool want_tight = prep->want_tight && leaf_n > 0;  // (no leaf holds a primitive: no tight tree either)
+    const size_t unb = (size_t)prep->unbounded, g0 = n_ts - unb, g1 = n_ss + unb;
+    const bool near_group = prep->pads.near_on && n_ss > 0;  // (a near tree without a sphere would be the far tree again)
+    const size_t tight_n = want_tight ? g0 + g1 + (near_group ? g1 : 0) : 0;
+    if ((int64_t)(leaf_n + tight_n) < min_items || n_nodes >= 0x7FFFFFFFull) return false;
     rtp::Prepared::DeviceTrees dev;
-    const size_t n_bvh = rtgb::node_count(prep->leaf_items), n_tight = prep->want_tight ? rtgb::node_count(prep->tight_items) : 0;
+    auto ok = [](hipError_t e) { return e == hipSuccess; };
+    if (upload(ctx, ctx->gb_flat, flat.nodes.data(), n_nodes * sizeof(rtf::FlatNode)) != RT_OK) return false;
+    const unsigned grid = (unsigned)((n_nodes + 255) / 256);
+    const size_t n_bvh = rtgb::node_count(leaf_n, leaf0, leaf_n);
     if (ensure(ctx, ctx->gb_bvh, n_bvh * sizeof(rtb::Node)) != RT_OK) return false;
-    if (n_bvh && rtgb::build_on_device(prep->leaf_items, (rtb::Node*)ctx->gb_bvh.p, &dev.bvh_levels, &dev.near_root) != 1) return false;
+    if (leaf_n) {
+        rtgb::Build b;
+        if (!b.alloc(leaf_n) || !ok(hipMemset(b.counters(), 0, 16))) return false;
+        hipLaunchKernelGGL(rtgb::k_leaf_items, dim3(grid), dim3(256), 0, 0, (const rtf::FlatNode*)ctx->gb_flat.p, (uint32_t)n_nodes, b.items(),
+                           (uint32_t)leaf0, b.counters());
+        if (b.run(leaf0, leaf_n, (rtb::Node*)ctx->gb_bvh.p, &dev.bvh_levels, &dev.near_root) != 1) return false;
+    }
     dev.bvh_nodes = ctx->gb_bvh.p, dev.n_bvh = n_bvh;
-    bool tight = n_tight > 0 && n_bvh > 0;  // (no leaf holds a primitive: no tight tree either)
+    bool tight = tight_n > 0;
     if (tight) {
-        if (ensure(ctx, ctx->gb_tight, n_tight * sizeof(rtb::Node)) != RT_OK || ensure(ctx, ctx->gb_tight_q, n_tight * sizeof(rtb::QNode)) != RT_OK)
+        const size_t n_tight = rtgb::node_count(tight_n, g0, g0 + g1);
+        if (upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48) != RT_OK || upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96) != RT_OK ||
+            upload(ctx, ctx->tri_slot_id, flat.tri_slot_id.data(), n_ts * 4) != RT_OK ||
+            upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), n_ss * 4) != RT_OK ||
+            upload(ctx, ctx->gb_unb, prep->tri_unbounded.data(), n_ts) != RT_OK || ensure(ctx, ctx->tri_slot_leaf, n_ts * 4) != RT_OK ||
+            ensure(ctx, ctx->sphere_slot_leaf, n_ss * 4) != RT_OK || ensure(ctx, ctx->gb_tight, n_tight * sizeof(rtb::Node)) != RT_OK ||
+            ensure(ctx, ctx->gb_tight_q, n_tight * sizeof(rtb::QNode)) != RT_OK)
             return false;
-        if (rtgb::build_on_device(prep->tight_items, (rtb::Node*)ctx->gb_tight.p, &dev.tight_levels, &dev.near_root) != 1) return false;
+        {
+            rtgb::Build b;
+            if (!b.alloc(tight_n) || !ok(hipMemset(b.counters(), 0, 16))) return false;
+            hipLaunchKernelGGL(rtgb::k_tight_items, dim3(grid), dim3(256), 0, 0, (const rtf::FlatNode*)ctx->gb_flat.p, (uint32_t)n_nodes,
+                               (const unsigned char*)ctx->tris_aos.p, (const unsigned char*)ctx->spheres_aos.p, (const int32_t*)ctx->tri_slot_id.p,
+                               (const int32_t*)ctx->sphere_slot_id.p, (const uint8_t*)ctx->gb_unb.p, prep->pads, near_group, b.items(),
+                               (uint32_t)g0, (uint32_t)(g0 + g1), b.counters(), (int32_t*)ctx->tri_slot_leaf.p, (int32_t*)ctx->sphere_slot_leaf.p);
+            if (b.run(g0, g0 + g1, (rtb::Node*)ctx->gb_tight.p, &dev.tight_levels, &dev.near_root) != 1) return false;
+        }
         tight = dev.tight_levels <= rtb::MAX_LEVELS &&
                 rtgb::quantize_on_device((const rtb::Node*)ctx->gb_tight.p, n_tight, (rtb::QNode*)ctx->gb_tight_q.p, dev.base, dev.step);
-        if (hipDeviceSynchronize() != hipSuccess) return false;
-        release(ctx->gb_tight);  // (the fp32 form is only the quantiser's input)
+        if (!ok(hipDeviceSynchronize())) return false;
+        if (!keep_fp32) release(ctx->gb_tight);  // (the fp32 form is only the quantiser's input)
+        if (tight) dev.tight_q_nodes = ctx->gb_tight_q.p, dev.n_tight = n_tight, dev.slot_leaf_on_device = true;
     }
-    if (tight) {
-        dev.tight_q_nodes = ctx->gb_tight_q.p, dev.n_tight = n_tight;
-    } else {
-        dev.near_root = 0, dev.tight_levels = 0;
-        prep->tri_slot_leaf.clear(), prep->sphere_slot_leaf.clear();
-    }
+    if (!tight) dev.near_root = 0, dev.tight_levels = 0;
+    dev.flat_nodes = ctx->gb_flat.p;
     dev.on = true;
     prep->dev = dev;
-    prep->leaf_items = rtb::Items(), prep->tight_items = rtb::Items();
     return true;
 }
 
@@ -686,8 +732,10 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     });
     // the copy of the accel array the GPU flatten worked on is not needed once the scene is up (or refused), nor are
     // the device builder's arrays (upload_prepared has copied them into the geometry image)
-    if ((ctx->accel_tmp.p || ctx->gb_bvh.p || ctx->gb_tight.p || ctx->gb_tight_q.p) && hipSetDevice(ctx->device) == hipSuccess)
-        release(ctx->accel_tmp), release(ctx->gb_bvh), release(ctx->gb_tight), release(ctx->gb_tight_q);
+    if ((ctx->accel_tmp.p || ctx->gb_bvh.p || ctx->gb_tight.p || ctx->gb_tight_q.p || ctx->gb_flat.p || ctx->gb_unb.p) &&
+        hipSetDevice(ctx->device) == hipSuccess)
+        release(ctx->accel_tmp), release(ctx->gb_bvh), release(ctx->gb_tight), release(ctx->gb_tight_q), release(ctx->gb_flat),
+            release(ctx->gb_unb);
     return rc;
 }
 static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
@@ -724,9 +772,12 @@ static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const v
     if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
     if (opt.defer_trees) {
         const auto t1 = std::chrono::steady_clock::now();
-        const bool on_device = prep.leaf_items.items.size() + prep.tight_items.items.size() >= (size_t)ctx->gpu_build_min &&
-                               hipSetDevice(ctx->device) == hipSuccess && build_trees_on_device(ctx, &prep);
-        if (!on_device) rtp::finish_trees_on_host(&prep);
+        const bool on_device = hipSetDevice(ctx->device) == hipSuccess &&
+                               build_trees_on_device(ctx, &prep, spheres, n_spheres, triangles, n_triangles, ctx->gpu_build_min);
+        if (!on_device) {
+            rtp::make_items_on_host(&prep, (const unsigned char*)spheres, (const unsigned char*)triangles);
+            rtp::finish_trees_on_host(&prep);
+        }
         if (std::getenv("RT_PREP_TIMING"))
             std::fprintf(stderr, "[rt prepare] %-28s %8.1f ms\n", on_device ? "both trees (SAH) on the GPU" : "both trees (SAH), host",
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
@@ -822,81 +873,93 @@ int rt_check_gpu_build(rt_ctx* ctx, const void* spheres, int n_spheres, const vo
     std::string msg;
     int result = 1;
     const int rc = no_throw(ctx, &msg, [&]() -> int {
-        rtp::Prepared prep;
+        // the host's trees, then the upload's own device route on a second preparation of the same arrays
+        rtp::Prepared host, prep;
         rtp::Options opt;
-        opt.tight_min_nodes = tight_min_nodes, opt.defer_trees = true;
-        const int r = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
-                                   accel_len, opt, &prep, &msg);
+        opt.tight_min_nodes = tight_min_nodes;
+        int r = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel, accel_len,
+                             opt, &host, &msg);
         if (r != RT_OK) return r;
-        const rtb::Items leaf = prep.leaf_items, tight = prep.tight_items;  // (the host build permutes its copy)
-        const bool want_tight = prep.want_tight;
-        rtb::Bvh host_tight;
-        {   // the host's tight tree before prepare's own post-conditions may drop it
-            rtb::Items t = tight;
-            if (want_tight) rtb::detail::build_items(t.items, t.split, &host_tight, t.split2);
-        }
-        rtp::finish_trees_on_host(&prep);
-        if (hipSetDevice(ctx->device) != hipSuccess) return RT_ERR_DEVICE;
-        struct Cmp {
-            const char* name;
-            const rtb::Items* items;
-            const rtb::Bvh* host;
-        } const trees[2] = {{"re-treed leaves", &leaf, &prep.bvh}, {"tight tree", &tight, &host_tight}};
-        for (const Cmp& t : trees) {
-            if (t.items->items.empty()) continue;
-            const size_t n_nodes = rtgb::node_count(*t.items);
-            if (n_nodes != t.host->nodes.size()) {
-                msg = std::string(t.name) + ": node counts differ";
+        opt.defer_trees = true;
+        r = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel, accel_len, opt,
+                         &prep, &msg);
+        if (r != RT_OK) return r;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return RT_ERR_DEVICE;
+        ctx->has_scene = false;  // (the route writes the context's record and slot buffers)
+        if (!build_trees_on_device(ctx, &prep, spheres, n_spheres, triangles, n_triangles, 0, true)) {
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                msg = std::string("HIP error in the device build: ") + hipGetErrorString(e);
                 return RT_ERR_DEVICE;
             }
-            rtgb::Buffers mem;
-            rtb::Node* d_nodes = mem.get<rtb::Node>(n_nodes);
-            rtb::QNode* d_q = mem.get<rtb::QNode>(n_nodes);
-            if (!d_nodes || !d_q) return RT_ERR_DEVICE;
+            result = 0;  // declined
+            return RT_OK;
+        }
+        const rtp::Prepared::DeviceTrees& dev = prep.dev;
+        auto differs = [&](const char* what, const void* d_ptr, const void* h_ptr, size_t bytes, size_t record) {
+            std::vector<unsigned char> got(bytes);
+            if (bytes && hipMemcpy(got.data(), d_ptr, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+                msg = std::string(what) + ": cannot read the device array";
+                return true;
+            }
+            if (bytes == 0 || std::memcmp(got.data(), h_ptr, bytes) == 0) return false;
+            size_t at = 0;
+            while (std::memcmp(got.data() + at * record, (const unsigned char*)h_ptr + at * record, record) == 0) at++;
+            msg = std::string(what) + " differ at record " + std::to_string(at) + " of " + std::to_string(bytes / record);
+            return true;
+        };
+        if (dev.n_bvh != host.bvh.nodes.size() || dev.n_tight != host.tight_q.nodes.size()) {
+            msg = "node counts differ: leaves " + std::to_string(dev.n_bvh) + " / " + std::to_string(host.bvh.nodes.size()) + ", tight " +
+                  std::to_string(dev.n_tight) + " / " + std::to_string(host.tight_q.nodes.size());
+            return RT_ERR_DEVICE;
+        }
+        if (dev.n_bvh && dev.bvh_levels != host.bvh.levels) {
+            msg = "depth of the re-treed leaves differs";
+            return RT_ERR_DEVICE;
+        }
+        if (differs("nodes of the re-treed leaves", dev.bvh_nodes, host.bvh.nodes.data(), dev.n_bvh * sizeof(rtb::Node), sizeof(rtb::Node)))
+            return RT_ERR_DEVICE;
+        if (dev.n_tight) {
+            if (dev.tight_levels != host.tight.levels || dev.near_root != host.tight.near_root) {
+                msg = "depth / second holder of the tight tree differ";
+                return RT_ERR_DEVICE;
+            }
+            if (std::memcmp(dev.base, host.tight_q.base, 12) != 0 || std::memcmp(dev.step, host.tight_q.step, 12) != 0) {
+                msg = "grids of the tight tree differ";
+                return RT_ERR_DEVICE;
+            }
+            if (differs("fp32 nodes of the tight tree", ctx->gb_tight.p, host.tight.nodes.data(), dev.n_tight * sizeof(rtb::Node), sizeof(rtb::Node)) ||
+                differs("16-bit nodes of the tight tree", dev.tight_q_nodes, host.tight_q.nodes.data(), dev.n_tight * sizeof(rtb::QNode),
+                        sizeof(rtb::QNode)) ||
+                differs("triangle slot -> leaf maps", ctx->tri_slot_leaf.p, host.tri_slot_leaf.data(), host.tri_slot_leaf.size() * 4, 4) ||
+                differs("sphere slot -> leaf maps", ctx->sphere_slot_leaf.p, host.sphere_slot_leaf.data(), host.sphere_slot_leaf.size() * 4, 4))
+                return RT_ERR_DEVICE;
+        }
+        // second route: the host's items, in the host's order, through the device builder
+        rtp::make_items_on_host(&prep, (const unsigned char*)spheres, (const unsigned char*)triangles);
+        const rtb::Items* src[2] = {&prep.leaf_items, &prep.tight_items};
+        const rtb::Bvh* want[2] = {&host.bvh, &host.tight};
+        for (int t = 0; t < 2; t++) {
+            const size_t n_nodes = rtgb::node_count(*src[t]);
+            if (n_nodes == 0 || want[t]->nodes.empty()) continue;
+            DevBuf& out = t ? ctx->gb_tight : ctx->gb_bvh;
+            if (ensure(ctx, out, n_nodes * sizeof(rtb::Node)) != RT_OK) return RT_ERR_DEVICE;
             int levels = 0;
             uint32_t near_root = 0;
-            const int took = rtgb::build_on_device(*t.items, d_nodes, &levels, &near_root);
-            if (took < 0) {
-                msg = std::string(t.name) + ": HIP error in the device build: " + hipGetErrorString(hipGetLastError());
+            if (rtgb::build_on_device(*src[t], (rtb::Node*)out.p, &levels, &near_root) != 1) {
+                msg = "the device builder refused host items it took from its own kernels";
                 return RT_ERR_DEVICE;
             }
-            if (took == 0) {
-                result = 0;
-                continue;
-            }
-            std::vector<rtb::Node> dev(n_nodes);
-            if (hipMemcpy(dev.data(), d_nodes, n_nodes * sizeof(rtb::Node), hipMemcpyDeviceToHost) != hipSuccess) return RT_ERR_DEVICE;
-            if (levels != t.host->levels || near_root != t.host->near_root) {
-                msg = std::string(t.name) + ": levels / second holder differ (" + std::to_string(levels) + " vs " +
-                      std::to_string(t.host->levels) + ")";
+            if (levels != want[t]->levels || differs(t ? "tight tree from host items" : "re-treed leaves from host items", out.p,
+                                                      want[t]->nodes.data(), n_nodes * sizeof(rtb::Node), sizeof(rtb::Node))) {
+                if (msg.empty()) msg = "depths differ (host items)";
                 return RT_ERR_DEVICE;
-            }
-            for (size_t i = 0; i < n_nodes; i++)
-                if (std::memcmp(&dev[i], &t.host->nodes[i], sizeof(rtb::Node)) != 0) {
-                    const rtb::Node &a = dev[i], &b = t.host->nodes[i];
-                    char line[256];
-                    std::snprintf(line, sizeof line, ": node %zu of %zu differs (device refs %08x %08x, host %08x %08x; lo.x %g %g | %g %g)", i,
-                                  n_nodes, a.ref[0], a.ref[1], b.ref[0], b.ref[1], a.lo[0][0], a.lo[0][1], b.lo[0][0], b.lo[0][1]);
-                    msg = std::string(t.name) + line;
-                    return RT_ERR_DEVICE;
-                }
-            if (t.host == &host_tight && !prep.tight_q.nodes.empty()) {  // the 16-bit grid form
-                float base[3], step[3];
-                if (!rtgb::quantize_on_device(d_nodes, n_nodes, d_q, base, step)) {
-                    msg = "tight tree: the device found no grid";
-                    return RT_ERR_DEVICE;
-                }
-                std::vector<rtb::QNode> q(n_nodes);
-                if (hipMemcpy(q.data(), d_q, n_nodes * sizeof(rtb::QNode), hipMemcpyDeviceToHost) != hipSuccess) return RT_ERR_DEVICE;
-                if (std::memcmp(base, prep.tight_q.base, 12) != 0 || std::memcmp(step, prep.tight_q.step, 12) != 0 ||
-                    std::memcmp(q.data(), prep.tight_q.nodes.data(), n_nodes * sizeof(rtb::QNode)) != 0) {
-                    msg = "tight tree: the 16-bit grid forms differ";
-                    return RT_ERR_DEVICE;
-                }
             }
         }
         return RT_OK;
     });
+    if (hipSetDevice(ctx->device) == hipSuccess)
+        release(ctx->gb_bvh), release(ctx->gb_tight), release(ctx->gb_tight_q), release(ctx->gb_flat), release(ctx->gb_unb);
     if (err && err_cap) {
         std::strncpy(err, msg.c_str(), err_cap - 1);
         err[err_cap - 1] = 0;

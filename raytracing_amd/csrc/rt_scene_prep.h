@@ -22,8 +22,8 @@ namespace rtp {
 struct Options {
     bool build_tight = true;
     int tight_min_nodes = 1000;  // flat node records from which a scene gets the tight tree
-    bool defer_trees = false;    // stop after the items of both trees: the caller builds them (rt_gpu_bvh.h) or calls
-                                 // finish_trees_on_host
+    bool defer_trees = false;    // stop before the items of both trees: the caller makes and builds them (rt_gpu_bvh.h)
+                                 // or calls make_items_on_host + finish_trees_on_host
 };
 
 struct Prepared {
@@ -41,7 +41,8 @@ struct Prepared {
     // what the two trees are built from (consumed by finish_trees_on_host; with Options::defer_trees left to the caller)
     rtb::Items leaf_items, tight_items;
     bool want_tight = false;
-    float near_lo[3] = {0, 0, 0}, near_hi[3] = {0, 0, 0};  // rtb::TightInput::near_lo / near_hi of the tight items
+    rtb::TightPads pads;  // pads and near region of the tight items (rt_bvh.h)
+    float near_lo[3] = {0, 0, 0}, near_hi[3] = {0, 0, 0};  // = pads.near_lo / near_hi
     // Trees the caller built on its GPU instead (rt_gpu_bvh.h): device arrays in the layouts of bvh.nodes and
     // tight_q.nodes; `bvh`, `tight` and `tight_q` above then stay empty.
     struct DeviceTrees {
@@ -54,8 +55,29 @@ struct Prepared {
         int tight_levels = 0;
         uint32_t near_root = 0;
         float base[3] = {0, 0, 0}, step[3] = {1, 1, 1};
+        // also on the device already (the item kernels read them): the flattened nodes, the caller's sphere / triangle
+        // records and slot id maps (in the context's own buffers), and -- if the tight tree was built -- the slot -> leaf maps
+        const void* flat_nodes = nullptr;
+        bool slot_leaf_on_device = false;
     } dev;
 };
+
+// The items of both trees on host threads (side by side).  spheres / triangles: the arrays prepare saw.
+inline void make_items_on_host(Prepared* out, const unsigned char* spheres, const unsigned char* triangles) {
+    const rtf::Flat& flat = out->flat;
+    out->leaf_items = rtb::Items(), out->tight_items = rtb::Items();
+    rtb::Crew tight_items;  // (joined whatever happens below; a failure in either thread is rethrown by finish())
+    if (out->want_tight)
+        tight_items.start([&] {
+            rtb::TightInput in;
+            static_cast<rtb::TightPads&>(in) = out->pads;
+            in.tris = triangles, in.spheres = spheres;
+            in.tri_unbounded = &out->tri_unbounded;
+            rtb::make_tight_items(flat, in, &out->tight_items, &out->tri_slot_leaf, &out->sphere_slot_leaf);
+        });
+    if (flat.nested) rtb::make_leaf_items(flat, &out->leaf_items);
+    tight_items.finish();
+}
 
 // The SAH builds over Prepared::leaf_items / tight_items on host threads (side by side: both builders fork further
 // below their first levels, neither reads what the other writes), then the 16-bit grid form of the tight tree.
@@ -216,29 +238,21 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
                             max_extent <= 1e6f;
     out->want_tight = want_tight;
     out->leaf_items = rtb::Items(), out->tight_items = rtb::Items();
-    rtb::Crew tight_items;  // (joined whatever happens below; a failure in either thread is rethrown by finish())
-    if (want_tight)
-        tight_items.start([&] {
-            rtb::TightInput in;
-            in.tris = triangles, in.spheres = spheres;
-            in.pad_tri = out->pad_tri, in.pad_sphere = out->pad_sphere;
-            in.tri_unbounded = &out->tri_unbounded;
-            // origins inside the root box grown by max_extent / 32 (hit points lie within the cull's pad, <= max_extent / 64
-            // there, of a primitive) walk the spheres' tree with the per-sphere pads (rt_bvh.h TightInput)
-            in.near_on = !flat.nodes.empty();
-            if (in.near_on) {
-                const rtf::FlatNode& root = flat.nodes[0];
-                const float rlo[3] = {root.minx, root.miny, root.minz}, rhi[3] = {root.maxx, root.maxy, root.maxz};
-                const float grow = 1.0f / 32.0f;  // (measured on Soup1M 4K: 1/32 48.0 ms, 1/2 47.8, 1 48.5, 2 50.2)
-                for (int k = 0; k < 3; k++) in.near_lo[k] = rlo[k] - max_extent * grow, in.near_hi[k] = rhi[k] + max_extent * grow;
-            }
-            for (int k = 0; k < 3; k++) out->near_lo[k] = in.near_lo[k], out->near_hi[k] = in.near_hi[k];
-            rtb::make_tight_items(flat, in, &out->tight_items, &out->tri_slot_leaf, &out->sphere_slot_leaf);
-        });
-    if (flat.nested) rtb::make_leaf_items(flat, &out->leaf_items);
-    tight_items.finish();
-    lap("items of both trees");
+    out->pads = rtb::TightPads();
+    out->pads.pad_tri = out->pad_tri, out->pads.pad_sphere = out->pad_sphere;
+    // origins inside the root box grown by max_extent / 32 (hit points lie within the cull's pad, <= max_extent / 64
+    // there, of a primitive) walk the spheres' tree with the per-sphere pads (rt_bvh.h TightPads)
+    out->pads.near_on = !flat.nodes.empty();
+    if (out->pads.near_on) {
+        const rtf::FlatNode& root = flat.nodes[0];
+        const float rlo[3] = {root.minx, root.miny, root.minz}, rhi[3] = {root.maxx, root.maxy, root.maxz};
+        const float grow = 1.0f / 32.0f;  // (measured on Soup1M 4K: 1/32 48.0 ms, 1/2 47.8, 1 48.5, 2 50.2)
+        for (int k = 0; k < 3; k++) out->pads.near_lo[k] = rlo[k] - max_extent * grow, out->pads.near_hi[k] = rhi[k] + max_extent * grow;
+    }
+    for (int k = 0; k < 3; k++) out->near_lo[k] = out->pads.near_lo[k], out->near_hi[k] = out->pads.near_hi[k];
     if (opt.defer_trees) return rtf::FLATTEN_OK;
+    make_items_on_host(out, spheres, triangles);
+    lap("items of both trees");
     finish_trees_on_host(out);
     lap("both trees (SAH), 16-bit grid");
     return rtf::FLATTEN_OK;
