@@ -85,6 +85,9 @@ struct rt_ctx {
                                   // them built on the GPU (rt_gpu_bvh.h); -1: never
     DevBuf gb_bvh, gb_tight, gb_tight_q;  // the device builder's results until upload_prepared has copied them
     DevBuf gb_flat, gb_unb;               // ... and two of its inputs: the flattened nodes, the unbounded-triangle flags
+    DevBuf gb_list;                       // containment_on_device: leaves that hold an unbounded triangle, its state words
+    // what containment_on_device left on the GPU for build_trees_on_device (one upload; cleared when it starts)
+    bool staged_records = false, staged_flat = false, staged_unb = false;
     int gpu_flatten_min = 65536;  // RT_OPTION_GPU_FLATTEN_MIN: accel arrays of at least this many floats are flattened on
                                   // the GPU (rt_gpu_flatten.h), smaller ones on the host (a launch per tree level costs
                                   // more than the whole host walk there); -1 = never
@@ -442,7 +445,8 @@ void rt_destroy(rt_ctx* ctx) {
                      &ctx->planes_aos, &ctx->tris_aos,   &ctx->lights,      &ctx->ticket,         &ctx->fb_rgb,
                      &ctx->fb_rgba8,   &ctx->fb_pid,     &ctx->fb_fid,      &ctx->fb_stats,
                      &ctx->tri_slot_leaf, &ctx->sphere_slot_leaf, &ctx->accel_tmp, &ctx->heat[0], &ctx->heat[1], &ctx->order,
-                     &ctx->gb_bvh,     &ctx->gb_tight,   &ctx->gb_tight_q,  &ctx->gb_flat,        &ctx->gb_unb};
+                     &ctx->gb_bvh,     &ctx->gb_tight,   &ctx->gb_tight_q,  &ctx->gb_flat,        &ctx->gb_unb,
+                     &ctx->gb_list};
     for (DevBuf* b : all) release(*b);
     for (DevBuf& b : ctx->ev) release(b);
     delete ctx;
@@ -524,8 +528,8 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     const int bvh_levels = dev.on ? dev.bvh_levels : bvh.levels;
     const int tight_levels = n_tight == 0 ? 0 : (dev.on ? dev.tight_levels : tight.levels);
     int rc;
-    const bool records_there = dev.on && dev.slot_leaf_on_device;  // (the tight tree's item kernel read them: build_trees_on_device)
-    if (!records_there) {
+    const bool records_there = dev.on && dev.slot_leaf_on_device;  // (the tight tree's item kernel wrote the slot -> leaf maps)
+    if (!ctx->staged_records) {  // (else: the device's containment check or item kernel read them from these buffers)
         if ((rc = upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48))) return rc;
         if ((rc = upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96))) return rc;
         if ((rc = upload(ctx, ctx->tri_slot_id, flat.tri_slot_id.data(), flat.tri_slot_id.size() * 4))) return rc;
@@ -651,6 +655,60 @@ static int upload_prepared(rt_ctx* ctx, const rtp::Prepared& prep, const void* s
     return RT_OK;
 }
 
+// The cull's preconditions (rt_scene_prep.h check_containment) on the GPU: one thread per leaf record runs the host's
+// own rule (rtp::leaf_contained).  state: [0] violated, [1] unbounded triangles, [2] entries of `list`.
+__global__ __launch_bounds__(256) void k_containment(const rtf::FlatNode* nodes, uint32_t n_nodes, const unsigned char* spheres,
+                                                     const unsigned char* triangles, const int32_t* sphere_slot_id, const int32_t* tri_slot_id,
+                                                     float slack, float max_extent, uint8_t* tri_unbounded, int32_t* list, uint32_t list_cap,
+                                                     uint32_t* state) {
+    const uint32_t ni = blockIdx.x * 256 + threadIdx.x;
+    if (ni >= n_nodes) return;
+    const bool fine = rtp::leaf_contained(nodes[ni], sphere_slot_id, tri_slot_id, spheres, triangles, slack, max_extent, [&](int slot) {
+        tri_unbounded[slot] = 1;
+        atomicAdd(state + 1, 1u);
+        const uint32_t at = atomicAdd(state + 2, 1u);
+        if (at < list_cap) list[at] = (int32_t)ni;
+    });
+    if (!fine) atomicExch(state, 1u);
+}
+// rtp::Options::containment for a single-GPU upload.  Leaves the records, slot id maps, flattened nodes and the
+// unbounded flags on the device for build_trees_on_device.  -1: declined (small scene, HIP error): the host checks.
+static int containment_on_device(rt_ctx* ctx, const rtf::Flat& flat, const float* extent, const void* spheres, int n_spheres,
+                                 const void* triangles, int n_triangles, std::vector<uint8_t>* tri_unbounded, std::vector<int32_t>* leaves) {
+    const size_t n_nodes = flat.nodes.size(), n_ts = flat.tri_slot_id.size(), n_ss = flat.sphere_slot_id.size();
+    if ((int64_t)(n_ts + n_ss) < (int64_t)ctx->gpu_build_min || n_nodes >= 0x7FFFFFFFull || hipSetDevice(ctx->device) != hipSuccess) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;  // (renders still reading the buffers below: upload_prepared's rule)
+    const size_t list_cap = 1 << 16;
+    if (upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48) != RT_OK || upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96) != RT_OK ||
+        upload(ctx, ctx->tri_slot_id, flat.tri_slot_id.data(), n_ts * 4) != RT_OK ||
+        upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), n_ss * 4) != RT_OK ||
+        upload(ctx, ctx->gb_flat, flat.nodes.data(), n_nodes * sizeof(rtf::FlatNode)) != RT_OK || ensure(ctx, ctx->gb_unb, n_ts) != RT_OK ||
+        ensure(ctx, ctx->gb_list, 16 + list_cap * 4) != RT_OK)
+        return -1;
+    ctx->staged_records = true;
+    uint32_t* const d_state = (uint32_t*)ctx->gb_list.p;
+    if (hipMemset(ctx->gb_unb.p, 0, std::max<size_t>(n_ts, 1)) != hipSuccess || hipMemset(d_state, 0, 16) != hipSuccess) return -1;
+    const float max_extent = std::fmax(extent[0], std::fmax(extent[1], extent[2]));
+    hipLaunchKernelGGL(k_containment, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, 0, (const rtf::FlatNode*)ctx->gb_flat.p,
+                       (uint32_t)n_nodes, (const unsigned char*)ctx->spheres_aos.p, (const unsigned char*)ctx->tris_aos.p,
+                       (const int32_t*)ctx->sphere_slot_id.p, (const int32_t*)ctx->tri_slot_id.p, max_extent * (1.0f / 4096.0f), max_extent,
+                       (uint8_t*)ctx->gb_unb.p, (int32_t*)(d_state + 4), (uint32_t)list_cap, d_state);
+    uint32_t state[4];
+    if (hipMemcpy(state, d_state, 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (state[0]) return 0;
+    if (state[2] > list_cap) return -1;  // (tens of thousands of unbounded triangles: the host's walk)
+    if (state[1]) {  // rare: the host marks the leaves in its copy of the tree and needs the flags for its own item rules
+        leaves->resize(state[2]);
+        if (hipMemcpy(tri_unbounded->data(), ctx->gb_unb.p, n_ts, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(leaves->data(), d_state + 4, (size_t)state[2] * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        std::sort(leaves->begin(), leaves->end());
+    }
+    ctx->staged_flat = state[1] == 0;  // (marks change the host's nodes: build_trees_on_device sends them again)
+    ctx->staged_unb = true;
+    return 1;
+}
+
 // Both derived trees on ctx's GPU (rt_gpu_bvh.h): items made by kernels from the flattened nodes and the caller's
 // records, the SAH builds, the 16-bit grid form -- with prepare's post-conditions (rtp::finish_trees_on_host).
 // prep: as rtp::prepare leaves it with Options::defer_trees.  False: too small for min_items, or the device declined
@@ -676,7 +734,8 @@ static bool build_trees_on_device(rt_ctx* ctx, rtp::Prepared* prep, const void* 
     if ((int64_t)(leaf_n + tight_n) < min_items || n_nodes >= 0x7FFFFFFFull) return false;
     rtp::Prepared::DeviceTrees dev;
     auto ok = [](hipError_t e) { return e == hipSuccess; };
-    if (upload(ctx, ctx->gb_flat, flat.nodes.data(), n_nodes * sizeof(rtf::FlatNode)) != RT_OK) return false;
+    if (!ok(hipDeviceSynchronize())) return false;  // (renders still reading the buffers below: upload_prepared's rule)
+    if (!ctx->staged_flat && upload(ctx, ctx->gb_flat, flat.nodes.data(), n_nodes * sizeof(rtf::FlatNode)) != RT_OK) return false;
     const unsigned grid = (unsigned)((n_nodes + 255) / 256);
     const size_t n_bvh = rtgb::node_count(leaf_n, leaf0, leaf_n);
     if (ensure(ctx, ctx->gb_bvh, n_bvh * sizeof(rtb::Node)) != RT_OK) return false;
@@ -691,10 +750,13 @@ static bool build_trees_on_device(rt_ctx* ctx, rtp::Prepared* prep, const void* 
     bool tight = tight_n > 0;
     if (tight) {
         const size_t n_tight = rtgb::node_count(tight_n, g0, g0 + g1);
-        if (upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48) != RT_OK || upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96) != RT_OK ||
-            upload(ctx, ctx->tri_slot_id, flat.tri_slot_id.data(), n_ts * 4) != RT_OK ||
-            upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), n_ss * 4) != RT_OK ||
-            upload(ctx, ctx->gb_unb, prep->tri_unbounded.data(), n_ts) != RT_OK || ensure(ctx, ctx->tri_slot_leaf, n_ts * 4) != RT_OK ||
+        if (!ctx->staged_records &&
+            (upload(ctx, ctx->spheres_aos, spheres, (size_t)n_spheres * 48) != RT_OK || upload(ctx, ctx->tris_aos, triangles, (size_t)n_triangles * 96) != RT_OK ||
+             upload(ctx, ctx->tri_slot_id, flat.tri_slot_id.data(), n_ts * 4) != RT_OK ||
+             upload(ctx, ctx->sphere_slot_id, flat.sphere_slot_id.data(), n_ss * 4) != RT_OK))
+            return false;
+        ctx->staged_records = true;
+        if ((!ctx->staged_unb && upload(ctx, ctx->gb_unb, prep->tri_unbounded.data(), n_ts) != RT_OK) || ensure(ctx, ctx->tri_slot_leaf, n_ts * 4) != RT_OK ||
             ensure(ctx, ctx->sphere_slot_leaf, n_ss * 4) != RT_OK || ensure(ctx, ctx->gb_tight, n_tight * sizeof(rtb::Node)) != RT_OK ||
             ensure(ctx, ctx->gb_tight_q, n_tight * sizeof(rtb::QNode)) != RT_OK)
             return false;
@@ -735,7 +797,7 @@ int rt_upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void*
     if ((ctx->accel_tmp.p || ctx->gb_bvh.p || ctx->gb_tight.p || ctx->gb_tight_q.p || ctx->gb_flat.p || ctx->gb_unb.p) &&
         hipSetDevice(ctx->device) == hipSuccess)
         release(ctx->accel_tmp), release(ctx->gb_bvh), release(ctx->gb_tight), release(ctx->gb_tight_q), release(ctx->gb_flat),
-            release(ctx->gb_unb);
+            release(ctx->gb_unb), release(ctx->gb_list);
     return rc;
 }
 static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
@@ -767,6 +829,11 @@ static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const v
     // the two derived trees of a large scene are built on the GPU (rt_gpu_bvh.h; bit-identical to the host builder's,
     // tests/test_gpu_build.py); a multi-GPU context replicates host arrays and builds on the host threads
     opt.defer_trees = ctx->gpu_build_min >= 0 && !ctx->multi;
+    ctx->staged_records = ctx->staged_flat = ctx->staged_unb = false;
+    if (opt.defer_trees)  // ... and so are the cull's preconditions (same rule, rtp::leaf_contained)
+        opt.containment = [&](const rtf::Flat& flat, const float* extent, std::vector<uint8_t>* tri_unbounded, std::vector<int32_t>* leaves) {
+            return containment_on_device(ctx, flat, extent, spheres, n_spheres, triangles, n_triangles, tri_unbounded, leaves);
+        };
     int rc = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel,
                           accel_len, opt, &prep, &err, flat_given);
     if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
@@ -881,11 +948,29 @@ int rt_check_gpu_build(rt_ctx* ctx, const void* spheres, int n_spheres, const vo
                              opt, &host, &msg);
         if (r != RT_OK) return r;
         opt.defer_trees = true;
+        ctx->has_scene = false;  // (the route writes the context's record and slot buffers)
+        ctx->staged_records = ctx->staged_flat = ctx->staged_unb = false;
+        const int min_before = ctx->gpu_build_min;
+        ctx->gpu_build_min = 0;
+        int device_checked = -1;
+        opt.containment = [&](const rtf::Flat& flat, const float* extent, std::vector<uint8_t>* tri_unbounded, std::vector<int32_t>* leaves) {
+            return device_checked = containment_on_device(ctx, flat, extent, spheres, n_spheres, triangles, n_triangles, tri_unbounded, leaves);
+        };
         r = rtp::prepare((const unsigned char*)spheres, n_spheres, (const unsigned char*)triangles, n_triangles, accel, accel_len, opt,
                          &prep, &msg);
+        ctx->gpu_build_min = min_before;
         if (r != RT_OK) return r;
         if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return RT_ERR_DEVICE;
-        ctx->has_scene = false;  // (the route writes the context's record and slot buffers)
+        if (prep.flat.nested && device_checked < 0) {
+            msg = "the device declined the containment check";
+            return RT_ERR_DEVICE;
+        }
+        if (prep.contained != host.contained || prep.unbounded != host.unbounded || prep.tri_unbounded != host.tri_unbounded ||
+            prep.flat.nodes.size() != host.flat.nodes.size() ||
+            std::memcmp(prep.flat.nodes.data(), host.flat.nodes.data(), host.flat.nodes.size() * sizeof(rtf::FlatNode)) != 0) {
+            msg = "containment check: the device's verdict, unbounded triangles or never-cull marks differ from the host's";
+            return RT_ERR_DEVICE;
+        }
         if (!build_trees_on_device(ctx, &prep, spheres, n_spheres, triangles, n_triangles, 0, true)) {
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
@@ -958,8 +1043,9 @@ int rt_check_gpu_build(rt_ctx* ctx, const void* spheres, int n_spheres, const vo
         }
         return RT_OK;
     });
+    ctx->staged_records = ctx->staged_flat = ctx->staged_unb = false;
     if (hipSetDevice(ctx->device) == hipSuccess)
-        release(ctx->gb_bvh), release(ctx->gb_tight), release(ctx->gb_tight_q), release(ctx->gb_flat), release(ctx->gb_unb);
+        release(ctx->gb_bvh), release(ctx->gb_tight), release(ctx->gb_tight_q), release(ctx->gb_flat), release(ctx->gb_unb), release(ctx->gb_list);
     if (err && err_cap) {
         std::strncpy(err, msg.c_str(), err_cap - 1);
         err[err_cap - 1] = 0;

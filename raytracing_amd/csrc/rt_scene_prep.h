@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -22,6 +23,9 @@ namespace rtp {
 struct Options {
     bool build_tight = true;
     int tight_min_nodes = 1000;  // flat node records from which a scene gets the tight tree
+    // the containment check somewhere else (rt_mi355x.hip: on the GPU): (flat, extent, &tri_unbounded, &unbounded_leaves)
+    // -> 1 contained, 0 not, -1 declined: the host threads check
+    std::function<int(const rtf::Flat&, const float*, std::vector<uint8_t>*, std::vector<int32_t>*)> containment;
     bool defer_trees = false;    // stop before the items of both trees: the caller makes and builds them (rt_gpu_bvh.h)
                                  // or calls make_items_on_host + finish_trees_on_host
 };
@@ -113,7 +117,7 @@ inline void finish_trees_on_host(Prepared* out) {
 // to their pad) assume hits near the primitive, so a triangle whose reach exceeds max_extent / 512 -- a quarter
 // of the cull's pad; a sliver with angle below 2.4e-4 * longest edge / max_extent -- is treated as unbounded
 // too.  A NaN or zero normal never yields a hit and is not "unbounded".
-inline bool triangle_is_unbounded(const float* rec, float max_extent) {
+RT_BVH_HD inline bool triangle_is_unbounded(const float* rec, float max_extent) {
     double ratio, longest;
     if (!rtb::triangle_shape(rec, &ratio, &longest)) return false;
     if (!(ratio > 0) || !(ratio >= 1e-5)) return true;
@@ -125,46 +129,55 @@ inline bool triangle_is_unbounded(const float* rec, float max_extent) {
 // unbounded triangles.  Returns false if the cull must stay off.
 // Leaf records are independent: the upload runs this over node ranges on up to 16 threads (a million primitives
 // take 0.17 s on one core).
+// One leaf record (shared with the device's form of the check, rt_mi355x.hip k_containment): false = a primitive
+// outside its leaf box or a normal that is not the triangle's; on_unbounded(slot) for every unbounded triangle.
+template <class OnUnbounded>
+RT_BVH_HD inline bool leaf_contained(const rtf::FlatNode& fn, const int32_t* sphere_slot_id, const int32_t* tri_slot_id,
+                                     const unsigned char* spheres, const unsigned char* triangles, float slack, float max_extent,
+                                     OnUnbounded&& on_unbounded) {
+    const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = fn.meta & 0xFFFFFF;
+    if (kind == rtf::KIND_BRANCH) return true;
+    const float lo[3] = {fn.minx - slack, fn.miny - slack, fn.minz - slack};
+    const float hi[3] = {fn.maxx + slack, fn.maxy + slack, fn.maxz + slack};
+    for (int k = 0; k < count; k++) {
+        if (kind == rtf::KIND_SPHERE) {
+            const float* rec = (const float*)(spheres + (size_t)sphere_slot_id[first + k] * 48);
+            for (int c = 0; c < 3; c++)
+                if (!(rec[c] - rec[3] >= lo[c] && rec[c] + rec[3] <= hi[c]) || !(rec[3] >= 0)) return false;
+            continue;
+        }
+        const float* rec = (const float*)(triangles + (size_t)tri_slot_id[first + k] * 96);
+        for (int v = 0; v < 3; v++)
+            for (int c = 0; c < 3; c++) {
+                const float x = rec[4 * v + c];
+                if (!(x >= lo[c] && x <= hi[c])) return false;
+            }
+        // the stored normal must be the triangle's: IntersectTriangle intersects the plane through A
+        // with THAT normal, and the cull's proof needs the hit point on the triangle.  Measured as the
+        // distance of B and C from that plane, allowed up to 1/8 of the cull's pad (the reference's own
+        // sliver triangles reach 3e-3 rad, 0.003 units).  A NaN normal (zero-area triangle, 32 of them
+        // in the teapot) or a zero normal never produces a hit and is fine.
+        const float* n = rec + 12;
+        const double nn = sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+        for (int v = 1; v < 3 && nn == nn && nn > 0; v++) {
+            const double off = fabs(((double)rec[4 * v] - rec[0]) * n[0] + ((double)rec[4 * v + 1] - rec[1]) * n[1] +
+                                    ((double)rec[4 * v + 2] - rec[2]) * n[2]);
+            if (!(off <= 4.0 * slack * nn)) return false;
+        }
+        if (triangle_is_unbounded(rec, max_extent)) on_unbounded(first + k);
+    }
+    return true;
+}
 inline bool check_containment_range(const rtf::Flat& flat, const unsigned char* spheres, const unsigned char* triangles,
                                     float slack, float max_extent, size_t n0, size_t n1, std::vector<uint8_t>* tri_unbounded,
                                     std::vector<int32_t>* unbounded_leaves) {
-    for (size_t ni = n0; ni < n1; ni++) {
-        const rtf::FlatNode& fn = flat.nodes[ni];
-        const int kind = (fn.meta >> 29) & 3, count = (fn.meta >> 24) & 31, first = fn.meta & 0xFFFFFF;
-        if (kind == rtf::KIND_BRANCH) continue;
-        const float lo[3] = {fn.minx - slack, fn.miny - slack, fn.minz - slack};
-        const float hi[3] = {fn.maxx + slack, fn.maxy + slack, fn.maxz + slack};
-        for (int k = 0; k < count; k++) {
-            if (kind == rtf::KIND_SPHERE) {
-                const float* rec = (const float*)(spheres + (size_t)flat.sphere_slot_id[first + k] * 48);
-                for (int c = 0; c < 3; c++)
-                    if (!(rec[c] - rec[3] >= lo[c] && rec[c] + rec[3] <= hi[c]) || !(rec[3] >= 0)) return false;
-                continue;
-            }
-            const float* rec = (const float*)(triangles + (size_t)flat.tri_slot_id[first + k] * 96);
-            for (int v = 0; v < 3; v++)
-                for (int c = 0; c < 3; c++) {
-                    const float x = rec[4 * v + c];
-                    if (!(x >= lo[c] && x <= hi[c])) return false;
-                }
-            // the stored normal must be the triangle's: IntersectTriangle intersects the plane through A
-            // with THAT normal, and the cull's proof needs the hit point on the triangle.  Measured as the
-            // distance of B and C from that plane, allowed up to 1/8 of the cull's pad (the reference's own
-            // sliver triangles reach 3e-3 rad, 0.003 units).  A NaN normal (zero-area triangle, 32 of them
-            // in the teapot) or a zero normal never produces a hit and is fine.
-            const float* n = rec + 12;
-            const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
-            for (int v = 1; v < 3 && nn == nn && nn > 0; v++) {
-                const double off = std::fabs(((double)rec[4 * v] - rec[0]) * n[0] + ((double)rec[4 * v + 1] - rec[1]) * n[1] +
-                                             ((double)rec[4 * v + 2] - rec[2]) * n[2]);
-                if (!(off <= 4.0 * slack * nn)) return false;
-            }
-            if (triangle_is_unbounded(rec, max_extent)) {
-                (*tri_unbounded)[first + k] = 1;  // slots of different leaves: no two threads write the same byte
-                unbounded_leaves->push_back((int32_t)ni);
-            }
-        }
-    }
+    for (size_t ni = n0; ni < n1; ni++)
+        if (!leaf_contained(flat.nodes[ni], flat.sphere_slot_id.data(), flat.tri_slot_id.data(), spheres, triangles, slack, max_extent,
+                            [&](int slot) {
+                                (*tri_unbounded)[slot] = 1;  // slots of different leaves: no two threads write the same byte
+                                unbounded_leaves->push_back((int32_t)ni);
+                            }))
+            return false;
     return true;
 }
 inline bool check_containment(const rtf::Flat& flat, const unsigned char* spheres, const unsigned char* triangles,
@@ -218,7 +231,12 @@ inline int prepare(const unsigned char* spheres, int n_spheres, const unsigned c
     }
     out->tri_unbounded.assign(flat.tri_slot_id.size(), 0);
     std::vector<int32_t> unbounded_leaves;
-    out->contained = check_containment(flat, spheres, triangles, out->extent, &out->tri_unbounded, &unbounded_leaves);
+    int took = opt.containment && flat.nested ? opt.containment(flat, out->extent, &out->tri_unbounded, &unbounded_leaves) : -1;
+    if (took < 0) {
+        std::fill(out->tri_unbounded.begin(), out->tri_unbounded.end(), 0), unbounded_leaves.clear();
+        took = check_containment(flat, spheres, triangles, out->extent, &out->tri_unbounded, &unbounded_leaves) ? 1 : 0;
+    }
+    out->contained = took == 1;
     if (!out->contained) std::fill(out->tri_unbounded.begin(), out->tri_unbounded.end(), 0);  // no cull: nothing to protect
     out->unbounded = (int64_t)std::count(out->tri_unbounded.begin(), out->tri_unbounded.end(), 1);
     if (out->contained)

@@ -74,3 +74,19 @@ def test_negative_zero_bounds(rt):
     c[1::3, 1] = 0.0
     c[:, 2] += 0.7          # (no flat boxes: the reference's own R-tree builder throws on leaves of zero-volume pairs)
     assert rt.check_gpu_build(_scene_of_triangles(a, b, c)) == 1
+
+
+def test_a_scene_that_fails_the_containment_check(rt):
+    """Stored normals that are not the triangles': the cull's preconditions fail on the device as on the host (no tight
+    tree, no unbounded marks), the re-treed leaves are still built and equal."""
+    g = np.random.default_rng(9)
+    n = 30000
+    a = g.uniform(-6, 6, (n, 3)).astype(np.float32)
+    b = a + g.uniform(0.1, 0.5, (n, 3)).astype(np.float32)
+    c = a + g.uniform(0.1, 0.5, (n, 3)).astype(np.float32)
+    sc = _scene_of_triangles(a, b, c)
+    sc.trianglesData["Normal"][::7] = [0.0, 1.0, 0.0]
+    assert rt.check_gpu_build(sc) == 1
+    rt.SendPrimitivesToShader(sc)
+    info = rt.scene_info()
+    assert info["flags"] == 1 and info["tight_nodes"] == 0 and info["bvh_nodes"] > 0
