@@ -301,7 +301,10 @@ int rt_check_gpu_flatten(rt_ctx* ctx, const float* accel, int64_t accel_len, int
  * the node arrays, the depths, the second root holder and the 16-bit grid form bit for bit.  Returns 1 (identical), 0
  * (the device declined a tree: a large node of coincident centroids, which it leaves to the host's median split), a
  * refusal of the accel array as rt_upload_scene words it, or RT_ERR_DEVICE with the first difference in err /
- * rt_last_error.  Used by the tests.  No counterpart in the reference (its tree arrives built, RTree.cs:180-377). */
+ * rt_last_error.  Also compares the device's form of the cull preconditions (verdict, unbounded triangles, never-cull
+ * marks) and the slot -> leaf maps.  The context's scene, if any, is gone afterwards (its buffers are the route's
+ * staging area): upload again.  Used by the tests.  No counterpart in the reference (its tree arrives built,
+ * RTree.cs:180-377). */
 int rt_check_gpu_build(rt_ctx* ctx, const void* spheres, int n_spheres, const void* triangles, int n_triangles, const float* accel,
                        int64_t accel_len, int tight_min_nodes, char* err, size_t err_cap);
 

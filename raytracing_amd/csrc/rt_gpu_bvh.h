@@ -63,6 +63,8 @@ struct BigNode {
     int axis, bin;                // the chosen split
     uint32_t cursor[2];           // next free place of each side (k_partition)
     uint32_t leaf_side[2];        // the child is a single item: it writes its ref into the node itself
+    uint32_t child_big[2];        // the child's record in the next level's list (NONE: small or a leaf): k_partition
+                                  // collects its centroid bounds on the way
 };
 struct Chunk {
     uint32_t node, first, count;
@@ -85,20 +87,24 @@ __device__ __forceinline__ void new_big(BigNode* nd, uint32_t b, uint32_t e, uin
     for (int k = 0; k < 3; k++) nd->cb_lo[k] = 0xFFFFFFFFu, nd->cb_hi[k] = 0u;
 }
 
+// centroid bounds of the group roots (the levels below get theirs from k_partition)
 __global__ __launch_bounds__(CHUNK) void k_bounds(const Item* items, const Chunk* chunks, BigNode* nodes) {
+    __shared__ uint32_t cb[6];
     const Chunk ch = chunks[blockIdx.x];
-    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+    if (threadIdx.x < 6) cb[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
     if (threadIdx.x < ch.count) {
         const Item it = items[ch.first + threadIdx.x];
-        for (int k = 0; k < 3; k++) lo[k] = hi[k] = f2o(0.5f * it.lo[k] + 0.5f * it.hi[k]);
-    }
-    for (int d = 32; d > 0; d >>= 1)
         for (int k = 0; k < 3; k++) {
-            lo[k] = min(lo[k], (uint32_t)__shfl_xor((int)lo[k], d, 64));
-            hi[k] = max(hi[k], (uint32_t)__shfl_xor((int)hi[k], d, 64));
+            const uint32_t c = f2o(0.5f * it.lo[k] + 0.5f * it.hi[k]);
+            atomicMin(&cb[k], c), atomicMax(&cb[3 + k], c);
         }
-    if ((threadIdx.x & 63) == 0 && threadIdx.x < ch.count)
-        for (int k = 0; k < 3; k++) atomicMin(&nodes[ch.node].cb_lo[k], lo[k]), atomicMax(&nodes[ch.node].cb_hi[k], hi[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicMin(&nodes[ch.node].cb_lo[threadIdx.x], cb[threadIdx.x]);
+    else if (threadIdx.x < 6)
+        atomicMax(&nodes[ch.node].cb_hi[threadIdx.x - 3], cb[threadIdx.x]);
 }
 
 __device__ __forceinline__ void clear_bins(uint32_t* bins, int i) {  // word i of a node's 3 x BINS x BIN_WORDS
@@ -166,16 +172,30 @@ __device__ __forceinline__ void set_child_box(Node* nd, int c, const Box& b) {
     for (int k = 0; k < 3; k++) nd->lo[k][c] = b.lo[k], nd->hi[k][c] = b.hi[k];
 }
 
+// four lanes per node: lanes 0..2 search one axis each (rtb::split_axis), lane 0 takes the cheapest in axis order
+// -- what the host's sequential search keeps -- and does the rest
 __global__ __launch_bounds__(64) void k_split(BigNode* nodes, uint32_t n_nodes, const uint32_t* bins, int level, Node* out,
                                               BigNode* next, Chunk* next_chunks, SmallWork* small, uint32_t next_parity, State* st) {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_nodes) return;
-    BigNode& nd = nodes[i];
-    const uint32_t* const table = bins + (size_t)i * (3 * BINS * BIN_WORDS);
+    const uint32_t i = (blockIdx.x * 64 + threadIdx.x) >> 2;
+    const int sub = (int)(threadIdx.x & 3), lane = (int)(threadIdx.x & 63);
+    const bool live = i < n_nodes;
+    BigNode& nd = nodes[live ? i : 0];
+    const uint32_t* const table = bins + (size_t)(live ? i : 0) * (3 * BINS * BIN_WORDS);
     const size_t n = nd.e - nd.b;
-    const rtb::detail::SplitChoice ch = rtb::detail::choose_split(
-        nd.scale, n, rtb::detail::child_capacity(level),
-        [&](int ax, int k, Box* bb, double* bw, size_t* bn) { bin_read(table, ax, k, bb, bw, bn); });
+    rtb::detail::SplitChoice mine{-1, -1};
+    double mine_cost = 1e300;
+    if (live && sub < 3)
+        rtb::detail::split_axis(
+            sub, nd.scale[sub], n, rtb::detail::child_capacity(level),
+            [&](int ax, int k, Box* bb, double* bw, size_t* bn) { bin_read(table, ax, k, bb, bw, bn); }, &mine_cost, &mine);
+    rtb::detail::SplitChoice ch{-1, -1};
+    double best = 1e300;
+    for (int ax = 0; ax < 3; ax++) {
+        const double c = __shfl(mine_cost, (lane & ~3) + ax, 64);
+        const int b = __shfl(mine.bin, (lane & ~3) + ax, 64);
+        if (c < best) best = c, ch.axis = ax, ch.bin = b;
+    }
+    if (!live || sub != 0) return;
     nd.axis = ch.axis, nd.bin = ch.bin;
     if (ch.axis < 0) {  // coincident centroids in a large node: the host's median split is not built here
         atomicExch(&st->declined, 1u);
@@ -202,12 +222,14 @@ __global__ __launch_bounds__(64) void k_split(BigNode* nodes, uint32_t n_nodes, 
         set_child_box(me, s, side[s]);
         const uint32_t cb = s ? mid : nd.b, ce = s ? nd.e : mid, cbase = s ? nd.base + cnt[0] : nd.base + 1;
         nd.leaf_side[s] = cnt[s] == 1;
+        nd.child_big[s] = NONE;
         if (cnt[s] == 1) continue;  // (the item writes its ref)
         me->ref[s] = cbase | (nocull[s] ? rtb::NOCULL : 0u);
         if (cnt[s] <= (uint32_t)SMALL_MAX) {
             small[atomicAdd(&st->n_small, 1u)] = SmallWork{cb, ce, cbase, (uint32_t)level + 1, next_parity};
         } else {
             const uint32_t id = atomicAdd(&st->n_big_next, 1u);
+            nd.child_big[s] = id;
             new_big(next + id, cb, ce, cbase);
             const uint32_t nch = (cnt[s] + CHUNK - 1) / CHUNK;
             const uint32_t at = atomicAdd(&st->n_chunks_next, nch);
@@ -217,11 +239,13 @@ __global__ __launch_bounds__(64) void k_split(BigNode* nodes, uint32_t n_nodes, 
     }
 }
 
-__global__ __launch_bounds__(CHUNK) void k_partition(const Item* items, Item* items_next, const Chunk* chunks, BigNode* nodes, Node* out) {
-    __shared__ uint32_t wave_cnt[CHUNK / 64][2], side_base[2];
+__global__ __launch_bounds__(CHUNK) void k_partition(const Item* items, Item* items_next, const Chunk* chunks, BigNode* nodes, Node* out,
+                                                     BigNode* next) {
+    __shared__ uint32_t wave_cnt[CHUNK / 64][2], side_base[2], cb[2][6];
     const Chunk ch = chunks[blockIdx.x];
     BigNode& nd = nodes[ch.node];
     const bool in = threadIdx.x < ch.count;
+    if (threadIdx.x < 12) cb[threadIdx.x / 6][threadIdx.x % 6] = threadIdx.x % 6 < 3 ? 0xFFFFFFFFu : 0u;
     Item it;
     int s = 0;
     if (in) {
@@ -238,7 +262,23 @@ __global__ __launch_bounds__(CHUNK) void k_partition(const Item* items, Item* it
         for (int w = 0; w < CHUNK / 64; w++) total += wave_cnt[w][threadIdx.x];
         side_base[threadIdx.x] = total ? atomicAdd(&nd.cursor[threadIdx.x], total) : 0u;
     }
+    // the centroid bounds of a large child, collected while its items pass through
+    if (in && nd.child_big[s] != NONE)
+        for (int k = 0; k < 3; k++) {
+            const uint32_t c = f2o(0.5f * it.lo[k] + 0.5f * it.hi[k]);
+            atomicMin(&cb[s][k], c), atomicMax(&cb[s][3 + k], c);
+        }
     __syncthreads();
+    if (threadIdx.x < 12) {
+        const int cs = (int)threadIdx.x / 6, f = (int)threadIdx.x % 6;
+        const uint32_t child = nd.child_big[cs];
+        if (child != NONE && wave_cnt[0][cs] + wave_cnt[1][cs] + wave_cnt[2][cs] + wave_cnt[3][cs]) {
+            if (f < 3)
+                atomicMin(&next[child].cb_lo[f], cb[cs][f]);
+            else
+                atomicMax(&next[child].cb_hi[f - 3], cb[cs][f]);
+        }
+    }
     if (!in) return;
     uint32_t at = side_base[s] + (uint32_t)__popcll((s ? m1 : m0) & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; w++) at += wave_cnt[w][s];
@@ -312,7 +352,8 @@ __global__ __launch_bounds__(64) void k_small(const Item* buf0, const Item* buf1
         double best_cost = 1e300;
         const size_t cap = rtb::detail::child_capacity(level);
         for (int ax = 0; ax < 3; ax++) {
-            for (int i = lane; i < 32 * BINS * BIN_WORDS; i += 64) clear_bins(&s_bins[0][0], i);
+            if (gen)  // (each segment clears its own table, its lanes taking turns)
+                for (int j = lane - sb; j < BINS * BIN_WORDS; j += sn) clear_bins(&s_bins[sid][0], j);
             __syncthreads();
             if (gen && scale[ax] > 0) {
                 uint32_t* const wd = &s_bins[sid][rtb::detail::bin_index(it.lo[ax], it.hi[ax], cb_lo[ax], scale[ax]) * BIN_WORDS];
@@ -354,7 +395,8 @@ __global__ __launch_bounds__(64) void k_small(const Item* buf0, const Item* buf1
             if (median) side = rank < sn / 2 ? 0 : 1;
         }
         // ---- boxes and counts of the two sides (bins 0 and 1 of the segment's table) ----
-        for (int i = lane; i < 32 * BINS * BIN_WORDS; i += 64) clear_bins(&s_bins[0][0], i);
+        if (gen)
+            for (int j = lane - sb; j < 2 * BIN_WORDS; j += sn) clear_bins(&s_bins[sid][0], j);
         __syncthreads();
         if (gen) {
             uint32_t* const wd = &s_bins[sid][side * BIN_WORDS];
@@ -658,13 +700,13 @@ public:
         int cur = 0;
         for (int level = 1; n_big > 0; level++) {
             if (level > rtb::MAX_LEVELS) return 0;
-            hipLaunchKernelGGL(k_bounds, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items_[cur], d_chunks_[cur], d_big_[cur]);
+            if (level == 1) hipLaunchKernelGGL(k_bounds, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items_[cur], d_chunks_[cur], d_big_[cur]);
             hipLaunchKernelGGL(k_scale, dim3(n_big), dim3(256), 0, 0, d_big_[cur], d_bins_);
             hipLaunchKernelGGL(k_bin, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items_[cur], d_chunks_[cur], d_big_[cur], d_bins_);
-            hipLaunchKernelGGL(k_split, dim3((n_big + 63) / 64), dim3(64), 0, 0, d_big_[cur], n_big, d_bins_, level, d_out, d_big_[cur ^ 1],
+            hipLaunchKernelGGL(k_split, dim3((n_big + 15) / 16), dim3(64), 0, 0, d_big_[cur], n_big, d_bins_, level, d_out, d_big_[cur ^ 1],
                                d_chunks_[cur ^ 1], d_small_, (uint32_t)(cur ^ 1), d_state_);
             hipLaunchKernelGGL(k_partition, dim3(n_chunks), dim3(CHUNK), 0, 0, d_items_[cur], d_items_[cur ^ 1], d_chunks_[cur], d_big_[cur],
-                               d_out);
+                               d_out, d_big_[cur ^ 1]);
             if (!ok(hipMemcpy(&state, d_state_, sizeof state, hipMemcpyDeviceToHost))) return -1;
             if (state.declined) return 0;
             n_big = state.n_big_next, n_chunks = state.n_chunks_next;

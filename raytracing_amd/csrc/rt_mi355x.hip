@@ -397,6 +397,7 @@ int rt_create(int device_id, rt_ctx** out) {
     if (const char* v = getenv("RT_PRIORITISE")) ctx->prioritise = atoi(v) != 0;
     if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development overrides
     if (const char* v = getenv("RT_GPU_FLATTEN_MIN")) ctx->gpu_flatten_min = atoi(v);
+    if (const char* v = getenv("RT_GPU_BUILD_MIN")) ctx->gpu_build_min = std::max(atoi(v), -1);
     if (const char* v = getenv("RT_COOP")) ctx->coop_shadows = std::min(std::max(atoi(v), 0), 2);
     if (const char* v = getenv("RT_HEAT")) ctx->use_heat = atoi(v) != 0;
     if (const char* v = getenv("RT_WF_MIN_NODES")) ctx->wf_min_nodes = std::max(0, atoi(v));
