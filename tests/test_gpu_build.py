@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name,params", [("TestScene1", None), ("TeapotScene", None), ("TeapotTable", None),
-                                         ("Soup", [3000, 30, 4]), ("Soup", [20000, 200, 8]), ("Soup", [150000, 1500, 8])])
+                                         ("Soup", [3000, 30, 4]), ("Soup", [20000, 200, 8]), ("Soup", [150000, 1500, 8]),
+                                         ("Soup", [1000000, 10000, 8])])   # (the last: BASELINE configs[2]'s scene, full size)
 def test_device_trees_equal_host_trees(name, params, rt, scene_of):
     assert rt.check_gpu_build(scene_of(name, params)) == 1
 
