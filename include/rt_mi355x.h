@@ -283,7 +283,9 @@ int rt_check_accel(const float* accel, int64_t accel_len, int n_spheres, int n_t
 /* The same with the primitives: everything rt_upload_scene decides on the host (cull preconditions ->
  * flags, unbounded_triangles, the re-treed leaves, the tight tree for scenes of at least tight_min_nodes
  * flattened nodes), followed by a structural self-check of both trees (exact unions, every slot reached
- * once, depth bound, tight boxes contain their primitive's accepted region + pad).  No context, no GPU. */
+ * once, depth bound, tight boxes contain their primitive's accepted region + pad) and a second build of both
+ * from the same items in another order, which must give the same node arrays (the device builder,
+ * RT_OPTION_GPU_BUILD_MIN, relies on that).  No context, no GPU. */
 int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, int n_triangles, const float* accel,
                    int64_t accel_len, int tight_min_nodes, rt_scene_info* info, char* err, size_t err_cap);
 

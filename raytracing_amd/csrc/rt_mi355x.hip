@@ -910,6 +910,27 @@ int rt_check_scene(const void* spheres, int n_spheres, const void* triangles, in
             if (msg.empty())
                 msg = rtp::verify_tree(prep.tight, &prep, (const unsigned char*)spheres, (const unsigned char*)triangles);
             if (msg.empty()) msg = rtp::verify_quantized(prep.tight, prep.tight_q);
+            if (msg.empty()) {
+                // the trees must not depend on the order their items arrive in (the device builder partitions with
+                // atomics, rt_gpu_bvh.h): the same items reversed and rotated give the same node arrays
+                rtp::make_items_on_host(&prep, (const unsigned char*)spheres, (const unsigned char*)triangles);
+                rtb::Items* src[2] = {&prep.leaf_items, &prep.tight_items};
+                const rtb::Bvh* want[2] = {&prep.bvh, &prep.tight};
+                for (int t = 0; t < 2 && msg.empty(); t++) {
+                    if (want[t]->nodes.empty()) continue;
+                    std::vector<rtb::detail::Item>& it = src[t]->items;
+                    const size_t bounds[4] = {0, src[t]->split, src[t]->split2, it.size()};
+                    for (int h = 0; h < 3; h++) {
+                        std::reverse(it.begin() + bounds[h], it.begin() + bounds[h + 1]);
+                        if (bounds[h + 1] - bounds[h] > 3) std::rotate(it.begin() + bounds[h], it.begin() + bounds[h] + (bounds[h + 1] - bounds[h]) / 3, it.begin() + bounds[h + 1]);
+                    }
+                    rtb::Bvh again;
+                    rtb::detail::build_items(it, src[t]->split, &again, src[t]->split2);
+                    if (again.nodes.size() != want[t]->nodes.size() || again.levels != want[t]->levels ||
+                        std::memcmp(again.nodes.data(), want[t]->nodes.data(), again.nodes.size() * sizeof(rtb::Node)) != 0)
+                        msg = t ? "the tight tree depends on the order of its items" : "the re-treed leaves depend on the order of their items";
+                }
+            }
             return msg.empty() ? (int)RT_OK : (int)RT_ERR_DEVICE;  // an internal inconsistency, never expected
         });
     if (err && err_cap) {

@@ -112,3 +112,42 @@ def test_malformed_arrays_are_refused(scene_of):
     empty = Scene(sc.spheresData[:0], sc.planesData, sc.trianglesData[:0], accel[:0], sc.lightsData, sc.cameraData)
     info = check_scene(empty, 0)
     assert info["n_nodes"] == 0 and info["tight_nodes"] == 0 and info["bvh_nodes"] == 0
+
+
+def test_trees_do_not_depend_on_the_order_of_their_items():
+    """rt_check_scene builds both trees a second time from reversed and rotated items and compares the node arrays (the
+    device builder partitions with atomics and relies on it).  The hard cases: coincident centroids -- copies of a
+    triangle in small groups (two-item nodes, the median split by (key, ref)) and 3000 concentric triangles (the median
+    split at the root of the leaves' tree) -- and box bounds of either zero."""
+    import numpy as np
+    from raytracing_amd import _native as N, host
+    from raytracing_amd.host import Scene
+
+    def scene(a, b, c):
+        tri = np.zeros(len(a), N.TRIANGLE_DT)
+        n = np.cross(b - a, c - a)
+        tri["PointA"], tri["PointB"], tri["PointC"] = a, b, c
+        tri["Normal"] = n / np.linalg.norm(n, axis=1, keepdims=True)
+        sph = np.zeros(0, N.SPHERE_DT)
+        return Scene(sph, np.zeros(0, N.PLANE_DT), tri, host.accel_from_structs(sph, tri), np.zeros(6, np.float32),
+                     host.camera_pack([0, 5, -20], [0, 0, 1], [1, 0, 0], 1.0, 1.6, 0.9, 64, 36))
+
+    g = np.random.default_rng(11)
+    a, b, c = [], [], []
+    for grp in range(60):
+        o = np.array([grp * 10.0, 0, 0]) + g.uniform(-1, 1, 3)
+        p = [o, o + g.uniform(0.5, 1, 3), o + g.uniform(0.5, 1, 3)]
+        for _ in range(int(g.integers(2, 41))):
+            a.append(p[0]), b.append(p[1]), c.append(p[2])
+    assert check_scene(scene(np.array(a, np.float32), np.array(b, np.float32), np.array(c, np.float32)), 0)["tight_nodes"] > 0
+    one = np.array([[-1, -1, -1], [1, -1, 1], [0, 1, 0]], np.float32)
+    scale = (1 + 0.001 * np.arange(3000, dtype=np.float32))[:, None]
+    assert check_scene(scene(*(one[k] * scale for k in range(3))), 0)["bvh_nodes"] > 0
+    n = 4000
+    a = g.uniform(-4, 4, (n, 3)).astype(np.float32)
+    a[::3, 0] = -0.0
+    a[1::3, 1] = 0.0
+    b = a + g.uniform(0.1, 0.5, (n, 3)).astype(np.float32)
+    c = a + g.uniform(0.1, 0.5, (n, 3)).astype(np.float32)
+    b[::3, 0] = -0.0
+    assert check_scene(scene(a, b, c), 0)["tight_nodes"] > 0
