@@ -143,8 +143,8 @@ enum {
     RT_OPTION_GPU_BUILD_MIN = 11, /* scenes whose two derived trees (re-treed leaves, tight tree) have at least this many
                                 items together (default 20000) get them built on the GPU: binned SAH, large nodes level by
                                 level, subtrees of <= 64 items by one wave each -- node arrays bit-identical to the host
-                                builder's (rt_check_gpu_build), which smaller scenes, multi-GPU contexts and trees the
-                                device declines still take.  -1: never */
+                                builder's (rt_check_gpu_build), which smaller scenes and trees the device declines still
+                                take.  A multi-GPU context builds on its first device and replicates.  -1: never */
     RT_OPTION_GPU_FLATTEN_MIN = 8 /* accel arrays of at least this many floats (default 65536) are validated and
                                 flattened on the GPU, level by level (bit-identical to the host's walk, which smaller
                                 arrays take and which still words every refusal); -1: never */

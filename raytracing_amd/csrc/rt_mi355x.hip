@@ -783,6 +783,29 @@ static bool build_trees_on_device(rt_ctx* ctx, rtp::Prepared* prep, const void* 
     return true;
 }
 
+// A multi-GPU context replicates the scene from host arrays: the trees built on the first device come back to the
+// host's vectors (what rtp::finish_trees_on_host would have left there).
+static bool device_trees_to_host(rt_ctx* ctx, rtp::Prepared* prep) {
+    const rtp::Prepared::DeviceTrees dev = prep->dev;
+    auto get = [](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+    prep->bvh = rtb::Bvh(), prep->tight = rtb::Bvh(), prep->tight_q = rtb::QBvh();
+    prep->bvh.nodes.resize(dev.n_bvh), prep->bvh.levels = dev.bvh_levels;
+    prep->tight_q.nodes.resize(dev.n_tight), prep->tight_q.near_root = dev.near_root;
+    prep->tight.levels = dev.tight_levels, prep->tight.near_root = dev.near_root;
+    for (int k = 0; k < 3; k++) {
+        prep->tight_q.base[k] = dev.base[k], prep->tight_q.step[k] = dev.step[k];
+        prep->tight.near_lo[k] = prep->near_lo[k], prep->tight.near_hi[k] = prep->near_hi[k];
+    }
+    prep->tri_slot_leaf.clear(), prep->sphere_slot_leaf.clear();
+    if (dev.slot_leaf_on_device) prep->tri_slot_leaf.resize(prep->flat.tri_slot_id.size()), prep->sphere_slot_leaf.resize(prep->flat.sphere_slot_id.size());
+    const bool ok = get(prep->bvh.nodes.data(), dev.bvh_nodes, dev.n_bvh * sizeof(rtb::Node)) &&
+                    get(prep->tight_q.nodes.data(), dev.tight_q_nodes, dev.n_tight * sizeof(rtb::QNode)) &&
+                    get(prep->tri_slot_leaf.data(), ctx->tri_slot_leaf.p, prep->tri_slot_leaf.size() * 4) &&
+                    get(prep->sphere_slot_leaf.data(), ctx->sphere_slot_leaf.p, prep->sphere_slot_leaf.size() * 4);
+    prep->dev = rtp::Prepared::DeviceTrees();
+    return ok;
+}
+
 static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const void* planes, int n_planes,
                         const void* triangles, int n_triangles, const float* accel, int64_t accel_len,
                         const float* lights, int lights_len);
@@ -828,8 +851,8 @@ static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const v
     rtp::Options opt;
     opt.build_tight = ctx->build_tight, opt.tight_min_nodes = ctx->tight_min_nodes;
     // the two derived trees of a large scene are built on the GPU (rt_gpu_bvh.h; bit-identical to the host builder's,
-    // tests/test_gpu_build.py); a multi-GPU context replicates host arrays and builds on the host threads
-    opt.defer_trees = ctx->gpu_build_min >= 0 && !ctx->multi;
+    // tests/test_gpu_build.py); a multi-GPU context builds on its first device and replicates from host copies
+    opt.defer_trees = ctx->gpu_build_min >= 0;
     ctx->staged_records = ctx->staged_flat = ctx->staged_unb = false;
     if (opt.defer_trees)  // ... and so are the cull's preconditions (same rule, rtp::leaf_contained)
         opt.containment = [&](const rtf::Flat& flat, const float* extent, std::vector<uint8_t>* tri_unbounded, std::vector<int32_t>* leaves) {
@@ -840,8 +863,9 @@ static int upload_scene(rt_ctx* ctx, const void* spheres, int n_spheres, const v
     if (rc != rtf::FLATTEN_OK) return fail(ctx, rc, err);
     if (opt.defer_trees) {
         const auto t1 = std::chrono::steady_clock::now();
-        const bool on_device = hipSetDevice(ctx->device) == hipSuccess &&
-                               build_trees_on_device(ctx, &prep, spheres, n_spheres, triangles, n_triangles, ctx->gpu_build_min);
+        bool on_device = hipSetDevice(ctx->device) == hipSuccess &&
+                         build_trees_on_device(ctx, &prep, spheres, n_spheres, triangles, n_triangles, ctx->gpu_build_min);
+        if (on_device && ctx->multi && !device_trees_to_host(ctx, &prep)) on_device = false;
         if (!on_device) {
             rtp::make_items_on_host(&prep, (const unsigned char*)spheres, (const unsigned char*)triangles);
             rtp::finish_trees_on_host(&prep);

@@ -109,3 +109,29 @@ def test_multi_context_device_resident_frame(devices, rt, scene_of):
             m.render_device(cam, 8, rgba8=only.data_ptr(), stream=stream.cuda_stream)
             stream.synchronize()
             assert np.array_equal(only.cpu().numpy(), single["rgba8"])
+
+
+def test_multi_context_with_trees_built_on_its_first_device(rt, scene_of):
+    """RT_OPTION_GPU_BUILD_MIN: a multi-GPU context builds both derived trees on its first device (csrc/rt_gpu_bvh.h),
+    brings them back to the host and replicates them -- same arrays as the host builder's, so the same frame, the
+    same scene info and the same counters as the single-GPU context, here forced on for a small scene and a soup."""
+    for name, params, depth in (("TeapotTable", None, 8), ("Soup", [30000, 300, 8], 4)):
+        sc = scene_of(name, params)
+        cam = sc.camera_for(192, 108)
+        rt.set_option(rt.OPTION_GPU_BUILD_MIN, -1)      # the single-GPU context: host threads
+        try:
+            rt.SendPrimitivesToShader(sc)
+            rt.PrepareRenderOpenGL(cam)
+            one, info_one = rt.RenderGL(depth), rt.scene_info()
+        finally:
+            rt.set_option(rt.OPTION_GPU_BUILD_MIN, 20000)
+        with RayTracer([0, 0, 0]) as m:
+            m.set_option(m.OPTION_GPU_BUILD_MIN, 0)
+            m.SendPrimitivesToShader(sc)
+            m.PrepareRenderOpenGL(cam)
+            out, info = m.RenderGL(depth), m.scene_info()
+        for k in ("bvh_nodes", "bvh_levels", "tight_nodes", "tight_levels", "flags", "unbounded_triangles"):
+            assert info[k] == info_one[k], (name, k)
+        for plane in ("primary_id", "final_id"):
+            assert np.array_equal(out[plane], one[plane]), (name, plane)
+        assert np.array_equal(out["rgb"].view(np.uint32), one["rgb"].view(np.uint32)), name
