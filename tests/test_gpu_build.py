@@ -91,3 +91,72 @@ def test_a_scene_that_fails_the_containment_check(rt):
     rt.SendPrimitivesToShader(sc)
     info = rt.scene_info()
     assert info["flags"] == 1 and info["tight_nodes"] == 0 and info["bvh_nodes"] > 0
+
+
+def _leaf(box, ids):
+    return [*box, 1.0, float(len(ids)), *map(float, ids)]
+
+
+def _branch(box, children):
+    out = [*box, 0.0, float(len(children))]
+    off = 8 + len(children)
+    offs = []
+    for c in children:
+        offs.append(float(off))
+        off += len(c)
+    out += offs
+    for c in children:
+        out += c
+    return out
+
+
+def test_hand_made_tree_with_mixed_and_long_leaves(rt):
+    """Shapes RTree.cs never produces but the format allows -- leaves that mix spheres and triangles, leaves of more
+    than 31 ids per class (the flatten cuts them into continuation records), an empty leaf -- with primitives that do
+    sit inside their leaf boxes: the device's containment check, item kernels and builds see the same records as the
+    host's and must give the same trees."""
+    g = np.random.default_rng(21)
+    S, T = 60, 400
+    sph = np.zeros(S, N.SPHERE_DT)
+    sph["Center"], sph["Radius"] = g.uniform(1, 9, (S, 3)), g.uniform(0.05, 0.3, S)
+    a = g.uniform(1, 9, (T, 3)).astype(np.float32)
+    b, c = a + g.uniform(-0.4, 0.4, (T, 3)).astype(np.float32), a + g.uniform(-0.4, 0.4, (T, 3)).astype(np.float32)
+    tri = np.zeros(T, N.TRIANGLE_DT)
+    n = np.cross(b - a, c - a)
+    tri["PointA"], tri["PointB"], tri["PointC"] = a, b, c
+    tri["Normal"] = n / np.linalg.norm(n, axis=1, keepdims=True)
+
+    def bounds(ids):
+        lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+        for i in ids:
+            if i < S:
+                p = [sph["Center"][i] - sph["Radius"][i], sph["Center"][i] + sph["Radius"][i]]
+            else:
+                p = [tri["PointA"][i - S], tri["PointB"][i - S], tri["PointC"][i - S]]
+            lo, hi = np.minimum(lo, np.min(p, axis=0)), np.maximum(hi, np.max(p, axis=0))
+        return [*(lo - 1e-3).astype(np.float32), *(hi + 1e-3).astype(np.float32)]
+
+    def union(boxes):
+        bx = np.array(boxes, np.float32)
+        return [*bx[:, :3].min(axis=0), *bx[:, 3:].max(axis=0)]
+
+    ids = list(g.permutation(S + T))
+    groups = [ids[:7], ids[7:127], ids[127:130], ids[130:300], ids[300:]]      # 120- and 170-id leaves: cut into pieces
+    leaves = [_leaf(bounds(grp), [int(i) for i in grp]) for grp in groups]
+    empty = _leaf([2, 2, 2, 3, 3, 3], [])
+    inner = _branch(union([bounds(groups[0]), bounds(groups[1]), [2, 2, 2, 3, 3, 3]]), [leaves[0], empty, leaves[1]])
+    root_box = union([bounds(grp) for grp in groups] + [[2, 2, 2, 3, 3, 3]])
+    tree = np.array(_branch(root_box, [inner, leaves[2], leaves[3], leaves[4]]), dtype=np.float32)
+    cam = host.camera_pack([5, 5, -15], [0, 0, 1], [1, 0, 0], 1.0, 1.6, 0.9, 64, 36)
+    sc = Scene(sph, np.zeros(0, N.PLANE_DT), tri, tree, np.array([5, 20, 5, 300, 300, 300], np.float32), cam)
+    assert rt.check_gpu_build(sc) == 1
+    rt.set_option(rt.OPTION_TIGHT_MIN_NODES, 0), rt.set_option(rt.OPTION_GPU_BUILD_MIN, 0)     # the upload's device route
+    try:
+        rt.SendPrimitivesToShader(sc)
+        info = rt.scene_info()
+        assert info["flags"] == 3 and info["tight_nodes"] > 0 and info["n_tri_slots"] == T and info["n_sphere_slots"] == S
+        rt.PrepareRenderOpenGL(cam)
+        fast, slow = rt.RenderGL(3), rt.RenderGL(3, stats=True)                                 # stats: the reference-order kernel
+        assert np.array_equal(fast["final_id"], slow["final_id"]) and np.array_equal(fast["rgb"].view(np.uint32), slow["rgb"].view(np.uint32))
+    finally:
+        rt.set_option(rt.OPTION_TIGHT_MIN_NODES, 1000), rt.set_option(rt.OPTION_GPU_BUILD_MIN, 20000)
