@@ -114,6 +114,7 @@ struct rt_ctx {
     DevBuf wf_org, wf_dir, wf_mult, wf_final, wf_list0, wf_list1, wf_blocked, wf_counters;
     DevBuf wf_list_tmp, wf_keys, wf_bins;  // binning of the continuing paths (k_wf_bin_*)
     int wf_bin_from = 0;  // lists of iterations >= this are sorted by origin cell (0: none)
+    bool wf_packet = true;  // primary rays of the staged pipeline as one packet per tile (RT_WF_PACKET=0, development: off)
     unsigned char* noalloc_scratch = nullptr;  // this device's address of `scratch` (hipGetSymbolAddress, rt_create)
     int wf_min_nodes = 1000;   // scenes with at least this many flat nodes get the tight tree and are candidates for
                                // the staged pipeline under AUTO (decided by measurement, tune_begin)
@@ -316,14 +317,23 @@ int launch_wavefront(rt_ctx* ctx, const RenderArgs& r, hipStream_t st, bool noal
     const int trace_grid = ctx->n_cus * ctx->wf_waves_per_cu;
     const size_t lds = (size_t)64 * std::max(a.scene.bvh_levels, 1) * 4;
     const int shade_grid = ctx->n_cus * 8;
+    // primary rays as one packet per tile (k_wf_closest_packet): the tight tree, and a camera its pads cover
+    bool packet = ctx->wf_packet && a.scene.tight != nullptr;
+    if (packet) {
+        float E = 0;
+        for (int k = 0; k < 3; k++) E = std::fmax(E, std::fabs(a.cam[k]) + a.scene.extent[k]);
+        packet = E <= a.scene.tight_e;
+    }
     for (int i = 0; i <= r.max_bounces; i++) {
         a.iter = i;
         // iteration 0 knows its size; later lists are at most as long as the frame
         const int g0 = (int)std::min<size_t>((size_t)trace_grid, (n0 + 63) / 64);
         // <true>: the scene holds unbounded triangles, refs are checked for the never-cull mark
         const bool unb = ctx->info.unbounded_triangles > 0;
-        hipLaunchKernelGGL(unb ? k_wf_closest<true> : k_wf_closest<false>, dim3(i == 0 ? g0 : trace_grid), dim3(64), lds,
-                           st, a);
+        if (i == 0 && packet)
+            hipLaunchKernelGGL(unb ? k_wf_closest_packet<true> : k_wf_closest_packet<false>, dim3((unsigned)(n0 / 64)), dim3(64), 0, st, a);
+        else
+            hipLaunchKernelGGL(unb ? k_wf_closest<true> : k_wf_closest<false>, dim3(i == 0 ? g0 : trace_grid), dim3(64), lds, st, a);
         if (a.n_lights > 0)
             hipLaunchKernelGGL(unb ? k_wf_any<true> : k_wf_any<false>, dim3(trace_grid), dim3(64), lds, st, a);
         const bool bin = a.bin_from > 0 && i + 1 >= a.bin_from && i < r.max_bounces;  // this iteration's output list
@@ -393,6 +403,7 @@ int rt_create(int device_id, rt_ctx** out) {
         const int t = atoi(v);
         if (t >= 1 && t <= 64) ctx->wf_waves_per_cu = t;
     }
+    if (const char* v = getenv("RT_WF_PACKET")) ctx->wf_packet = atoi(v) != 0;  // development
     if (const char* v = getenv("RT_WF_BIN_FROM")) ctx->wf_bin_from = std::max(atoi(v), 0);  // development
     if (const char* v = getenv("RT_PRIORITISE")) ctx->prioritise = atoi(v) != 0;
     if (const char* v = getenv("RT_TIGHT")) ctx->build_tight = atoi(v) != 0;  // development overrides

@@ -314,13 +314,14 @@ struct WfClosestJob {
         // (the tight ray lives on the tree's grid: the reference's test takes the ray as the shader forms it)
         return IntersectBoundingBox(make_box_ray(o, d), g.node_lo(leaf), g.node_hi(leaf));
     }
-    __device__ __forceinline__ void sphere(int slot) {
-        const float4 s = g.sphere(slot);
+    __device__ __forceinline__ void sphere(int slot) { sphere_is(slot, g.sphere(slot)); }
+    __device__ __forceinline__ void tri(int slot) { tri_is(slot, load_tri(g, slot)); }
+    // (the record already fetched: k_wf_closest_packet reads it once for the whole wave)
+    __device__ __forceinline__ void sphere_is(int slot, float4 s) {
         const float t = IntersectSphereT(o, d, v3(s.x, s.y, s.z), s.w);
         if (closer(t, 0, slot, t_lo, h) && leaf_passes(a.scene.sphere_slot_leaf, slot)) h.t = t, h.kind = 0, h.index = slot;
     }
-    __device__ __forceinline__ void tri(int slot) {
-        const TriG tg = load_tri(g, slot);
+    __device__ __forceinline__ void tri_is(int slot, const TriG& tg) {
         const float t = IntersectTriangleWindowed(o, d, tg.A, tg.B, tg.C, tg.N,
                                                   [&](float tt) { return closer(tt, 2, slot, t_lo, h); });
         if (closer(t, 2, slot, t_lo, h) && leaf_passes(a.scene.tri_slot_leaf, slot)) h.t = t, h.kind = 2, h.index = slot;
@@ -387,6 +388,99 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES_
     g.tight = a.scene.tight;
     WfClosestJob<GeomBvhT<UNB>> job{a, g, a.iter == 0 ? 0.0f : RT_EPSILON};
     wf_run(g, a.counters + 4 * a.iter + 1, wf_active_count(a), job);
+}
+
+// The primary rays of an 8x8 tile as ONE packet (iteration 0 on the tight tree).  Per-lane walks cost the same
+// whether their rays are neighbours or not: every lane fetches its own node (a gather) and the wave advances at the
+// pace of its votes.  The 64 primary rays of a tile share their origin and differ by a fraction of a degree, so
+// here the WAVE walks the tree once -- one current node, one stack (lane i of a register = entry i), node and
+// primitive addresses wave-uniform -- and every lane tests the boxes and primitives of the shared walk against its own
+// ray and its own closest hit so far.  A child is entered if any lane's ray meets it; of two, the one more lanes
+// enter first.  Each lane thereby tests a SUPERSET of the candidates of its own walk; results cannot differ: a hit
+// counts by the exact rule (primitive test + the reference's test of the slot's leaf box, leaf_passes), and the
+// closest hit is the minimum under closer()'s total order, whatever the order of the tests.
+// Lanes whose ray may not walk the tight tree (a direction component below 1e-30) take the exact tree exhaustively;
+// the host only launches this kernel for a camera inside E_build.
+// a 16-byte record at a wave-uniform address, through the scalar cache (read only: the geometry image is never
+// written while a render runs)
+__device__ __forceinline__ uint4 wf_uniform_load(const void* p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) u32x4* const_ptr;
+    const u32x4 v = *(const_ptr)(uintptr_t)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 wf_uniform_load_f4(const void* p) {
+    const uint4 u = wf_uniform_load(p);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+template <bool UNB>
+__global__ __launch_bounds__(64) void k_wf_closest_packet(const WfArgs a) {
+    constexpr uint32_t LEAF = 0x80000000u;
+    GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, 0};
+    g.tight = a.scene.tight;
+    WfClosestJob<GeomBvhT<UNB>> job{a, g, 0.0f};
+    const bool traced = job.setup(blockIdx.x * 64u + threadIdx.x);  // false: no pixel, or done (zero direction component)
+    const bool pk = traced && job.tight;
+    if (traced && !job.tight)
+        walk<false>(
+            g, a.scene.n_nodes, job.br, 3, false, nullptr,
+            [&](int slot) {
+                job.sphere(slot);
+                return false;
+            },
+            [&](int slot) {
+                job.tri(slot);
+                return false;
+            });
+    const unsigned long long pk_m = __ballot(pk);
+    if (pk_m) {
+        int stk = 0, sp = 0;
+        uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)job.root, __ffsll(pk_m) - 1);
+        for (;;) {
+            if (!(cur & LEAF)) {
+                const uint4* const node = g.tight + 2 * (size_t)(UNB ? (cur & rtb::INDEX_MASK) : cur);
+                const uint4 q0 = wf_uniform_load(node), q1 = wf_uniform_load(node + 1);
+                const uint32_t r0 = q1.z, r1 = q1.w;
+                const bool nc0 = UNB && rtb::ref_nocull(r0), nc1 = UNB && rtb::ref_nocull(r1);
+                float e0, e1;
+                const float th = job.h.t;
+                const bool h0 = pk & (r0 != LEAF) & SlabHitQ<0>(job.br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, job.t_lo, th, &e0, nc0);
+                const bool h1 = pk & (r1 != LEAF) & SlabHitQ<1>(job.br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, job.t_lo, th, &e1, nc1);
+                const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+                if (m0 && m1) {
+                    const int n0 = __popcll(m0 & ~m1) + __popcll(__ballot(h0 & h1 & (e0 <= e1)));
+                    const int n1 = __popcll(m1 & ~m0) + __popcll(__ballot(h0 & h1 & (e1 < e0)));
+                    const bool first0 = n0 >= n1;
+                    stk = (int)__lane_id() == sp ? (int)(first0 ? r1 : r0) : stk;
+                    sp++;
+                    cur = first0 ? r0 : r1;
+                    continue;
+                }
+                if (m0 | m1) {
+                    cur = m0 ? r0 : r1;
+                    continue;
+                }
+            } else {
+                const int kind = (cur >> 29) & 3, count = (cur >> 24) & 31, first = (int)(cur & 0xFFFFFF);
+                for (int k = 0; k < count; k++) {
+                    const int slot = first + k;
+                    if (kind == rtf::KIND_SPHERE) {
+                        const float4 sp4 = wf_uniform_load_f4(g.base + g.sph_off + slot);
+                        if (pk) job.sphere_is(slot, sp4);
+                    } else {
+                        const float4* const rec = g.base + g.tri_off + 3 * (size_t)slot;
+                        const float4 t0 = wf_uniform_load_f4(rec), t1 = wf_uniform_load_f4(rec + 1), t2 = wf_uniform_load_f4(rec + 2);
+                        TriG tg;  // (load_tri's unpacking)
+                        tg.A = v3(t0.x, t0.y, t0.z), tg.B = v3(t0.w, t1.x, t1.y), tg.C = v3(t1.z, t1.w, t2.x), tg.N = v3(t2.y, t2.z, t2.w);
+                        if (pk) job.tri_is(slot, tg);
+                    }
+                }
+            }
+            if (sp == 0) break;
+            cur = (uint32_t)__builtin_amdgcn_readlane(stk, --sp);
+        }
+    }
+    if (traced) job.finish();
 }
 
 // ------------------------------------------------------------------------------------------
