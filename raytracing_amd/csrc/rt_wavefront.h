@@ -91,6 +91,11 @@ __device__ __forceinline__ uint32_t wf_cell(const WfArgs& a, V3 x) {
 }
 
 constexpr uint32_t WF_NO_HIT = 3u << 28;
+// bit 27 of a packed hit (between kind and index, masked off by every reader).  On the hit of iteration 0: the closest
+// hit of this pixel's mirror bounce is known already (k_wf_closest_packet traced it: t in mult_b[p].w, hit in
+// final_[p].w); on the open hit of a continuing path: org_t[p].w / this word ARE that result -- the closest-hit stage of
+// the next iteration has nothing to do for it.
+constexpr uint32_t WF_PRE_BIT = 1u << 27;
 __device__ __forceinline__ uint32_t wf_pack_hit(int kind, int index) { return ((uint32_t)kind << 28) | (uint32_t)(index & 0xFFFFFF); }
 
 // work item k of iteration 0 -> local pixel index, or -1 outside the image (ragged right/top tiles)
@@ -113,6 +118,9 @@ __device__ __forceinline__ const uint32_t* wf_list_in(const WfArgs& a) { return 
 __device__ __forceinline__ uint32_t* wf_list_out(const WfArgs& a) { return (a.iter & 1) ? a.list[0] : a.list[1]; }
 __device__ __forceinline__ uint32_t wf_active_count(const WfArgs& a) { return a.iter == 0 ? a.n0 : a.counters[4 * a.iter]; }
 
+#ifndef RT_WF_EXACT_INLINE
+#define RT_WF_EXACT_INLINE __forceinline__
+#endif
 #ifndef RT_WF_VOTE
 #define RT_WF_VOTE 3  // a node step needs this many times as many lanes as stand at a leaf (wf_run)
 #endif
@@ -336,7 +344,6 @@ struct WfClosestJob {
         }
     }
     __device__ __forceinline__ bool setup(uint32_t k) {
-        const DevScene& S = a.scene;
         if (a.iter == 0) {
             int x, r;
             p = wf_pixel_of(a, k, &x, &r);
@@ -346,8 +353,30 @@ struct WfClosestJob {
         } else {
             p = (int)wf_list_in(a)[k];
             const float4 q0 = a.org_t[p], q1 = a.dir_hit[p];
+            if (__float_as_uint(q1.w) & WF_PRE_BIT) return false;  // traced with the primary packet (k_wf_closest_packet)
             o = v3(q0.x, q0.y, q0.z), d = v3(q1.x, q1.y, q1.z);
         }
+        if (begin()) return true;
+        // zero direction component etc.: the exact tree, exhaustively (rare)
+        walk_exact();
+        finish();
+        return false;
+    }
+    __device__ RT_WF_EXACT_INLINE void walk_exact() {
+        walk<false>(
+            g, a.scene.n_nodes, br, 3, false, nullptr,
+            [&](int slot) {
+                sphere(slot);
+                return false;
+            },
+            [&](int slot) {
+                tri(slot);
+                return false;
+            });
+    }
+    // the ray (o, d, t_lo) against the planes; true: it goes on to walk a tree (tight / root say which)
+    __device__ __forceinline__ bool begin() {
+        const DevScene& S = a.scene;
         br = make_box_ray_cull(o, d, v3(S.extent[0], S.extent[1], S.extent[2]), S.cull_scale);
         h = fresh_closest();
         for (int q = 0; q < S.n_planes; q++) {
@@ -361,18 +390,6 @@ struct WfClosestJob {
             if (tight) root = tight_root(S, o);
             return true;
         }
-        // zero direction component etc.: the exact tree, exhaustively (rare)
-        walk<false>(
-            g, S.n_nodes, br, 3, false, nullptr,
-            [&](int slot) {
-                sphere(slot);
-                return false;
-            },
-            [&](int slot) {
-                tri(slot);
-                return false;
-            });
-        finish();
         return false;
     }
 };
@@ -413,29 +430,17 @@ __device__ __forceinline__ float4 wf_uniform_load_f4(const void* p) {
     const uint4 u = wf_uniform_load(p);
     return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
 }
-template <bool UNB>
-__global__ __launch_bounds__(64) void k_wf_closest_packet(const WfArgs a) {
+// the shared walk for the lanes `mine` of the wave (rays that may walk the tight tree), once per root holder
+template <bool UNB, class Job>
+__device__ __forceinline__ void wf_packet_closest(const WfArgs& a, const GeomBvhT<UNB>& g, Job& job, bool mine) {
     constexpr uint32_t LEAF = 0x80000000u;
-    GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, 0};
-    g.tight = a.scene.tight;
-    WfClosestJob<GeomBvhT<UNB>> job{a, g, 0.0f};
-    const bool traced = job.setup(blockIdx.x * 64u + threadIdx.x);  // false: no pixel, or done (zero direction component)
-    const bool pk = traced && job.tight;
-    if (traced && !job.tight)
-        walk<false>(
-            g, a.scene.n_nodes, job.br, 3, false, nullptr,
-            [&](int slot) {
-                job.sphere(slot);
-                return false;
-            },
-            [&](int slot) {
-                job.tri(slot);
-                return false;
-            });
-    const unsigned long long pk_m = __ballot(pk);
-    if (pk_m) {
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t root = pass ? a.scene.tight_near_root : 0u;
+        if (pass && root == 0u) break;
+        const bool pk = mine && job.root == root;
+        if (!__ballot(pk)) continue;
         int stk = 0, sp = 0;
-        uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)job.root, __ffsll(pk_m) - 1);
+        uint32_t cur = root;
         for (;;) {
             if (!(cur & LEAF)) {
                 const uint4* const node = g.tight + 2 * (size_t)(UNB ? (cur & rtb::INDEX_MASK) : cur);
@@ -480,7 +485,42 @@ __global__ __launch_bounds__(64) void k_wf_closest_packet(const WfArgs a) {
             cur = (uint32_t)__builtin_amdgcn_readlane(stk, --sp);
         }
     }
+}
+
+template <bool UNB>
+__global__ __launch_bounds__(64) void k_wf_closest_packet(const WfArgs a) {
+    GeomBvhT<UNB> g{a.scene.geom, a.scene.tri_off, a.scene.sph_off, a.scene.bvh, 0};
+    g.tight = a.scene.tight;
+    WfClosestJob<GeomBvhT<UNB>> job{a, g, 0.0f};
+    const bool traced = job.setup(blockIdx.x * 64u + threadIdx.x);  // false: no pixel, or done (zero direction component)
+    if (traced && !job.tight) job.walk_exact();
+    wf_packet_closest<UNB>(a, g, job, traced && job.tight);
     if (traced) job.finish();
+    // ---- the mirror bounce of the pixels that hit ONE pure-specular plane (the reference scenes' mirror floors): the
+    // reflected rays are the primary rays of the camera's mirror image -- as good a packet as the first.  Their closest
+    // hits are found here and handed to k_wf_shade through WF_PRE_BIT; the next iteration's closest-hit stage skips them.
+    if (a.max_bounces < 1) return;
+    const bool on_plane = job.p >= 0 && job.h.kind == 1;
+    const unsigned long long plane_m = __ballot(on_plane);
+    if (!plane_m) return;
+    const int plane = __builtin_amdgcn_readlane(job.h.index, __ffsll(plane_m) - 1);
+    Closest hp = fresh_closest();
+    hp.kind = 1, hp.index = plane;  // (wave-uniform: the surface's record is one scalar fetch)
+    const Surface sf = resolve_surface(a.scene, hp);
+    if (!sf.pure) return;
+    const bool bounce = on_plane && job.h.index == plane;
+    WfClosestJob<GeomBvhT<UNB>> next{a, g, RT_EPSILON};
+    next.p = job.p;
+    next.o = job.o + job.h.t * job.d;           // as k_wf_shade forms the continuing ray
+    next.d = mirror_direction(sf, job.d);
+    const bool walks = bounce && next.begin() && next.tight;  // (other rays: the next iteration's per-lane stage)
+    if (!__ballot(walks)) return;
+    wf_packet_closest<UNB>(a, g, next, walks);
+    if (walks) {
+        ((float*)(a.mult_b + job.p))[3] = next.h.t;
+        ((uint32_t*)(a.final_ + job.p))[3] = wf_pack_hit(next.h.kind, next.h.index);
+        ((uint32_t*)(a.dir_hit + job.p))[3] = wf_pack_hit(job.h.kind, job.h.index) | WF_PRE_BIT;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -574,19 +614,21 @@ struct WfAnyJob {
             if (tight) root = tight_root(S, o);
             return true;
         }
-        if (!blocked)
-            walk<false>(
-                g, S.n_nodes, br, 3, false, nullptr,
-                [&](int slot) {
-                    sphere(slot);
-                    return blocked;
-                },
-                [&](int slot) {
-                    tri(slot);
-                    return blocked;
-                });
+        if (!blocked) walk_exact();
         finish();
         return false;
+    }
+    __device__ RT_WF_EXACT_INLINE void walk_exact() {
+        walk<false>(
+            g, a.scene.n_nodes, br, 3, false, nullptr,
+            [&](int slot) {
+                sphere(slot);
+                return blocked;
+            },
+            [&](int slot) {
+                tri(slot);
+                return blocked;
+            });
     }
 };
 
@@ -642,8 +684,12 @@ __global__ __launch_bounds__(256) void k_wf_shade(const WfArgs a) {
                     finalColor = finalColor + mirror_diffuse_term(S, sf, hitPos, in_shadow) * mult;
                 mult = mult * sf.specular;
                 const V3 refl = mirror_direction(sf, rayDirection);
-                a.org_t[p] = make_float4(hitPos.x, hitPos.y, hitPos.z, RT_FLT_BIG);
-                a.dir_hit[p] = make_float4(refl.x, refl.y, refl.z, __uint_as_float(WF_NO_HIT));
+                float next_t = RT_FLT_BIG;
+                uint32_t next_hit = WF_NO_HIT;
+                if (a.iter == 0 && (hit & WF_PRE_BIT))  // k_wf_closest_packet traced this bounce already
+                    next_t = ((const float*)(a.mult_b + p))[3], next_hit = ((const uint32_t*)(a.final_ + p))[3] | WF_PRE_BIT;
+                a.org_t[p] = make_float4(hitPos.x, hitPos.y, hitPos.z, next_t);
+                a.dir_hit[p] = make_float4(refl.x, refl.y, refl.z, __uint_as_float(next_hit));
                 a.mult_b[p] = make_float4(mult.x, mult.y, mult.z, 0);
                 a.final_[p] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0);
                 continues = true;
