@@ -140,6 +140,11 @@ enum {
                                 in compaction order.  Measured on the 1M-triangle soup at 4K: neither gains nor loses
                                 (47.7 ms both ways, profiles/r03_soup1m_binning_per_bounce.txt), hence off.  Pixels never
                                 depend on it; rt_render_device_noalloc ignores it */
+    RT_OPTION_PACKET_WALKS = 12, /* staged pipeline only.  1 (default): the primary rays of every 8x8 tile walk the tight tree
+                                as ONE packet (a shared walk, per-lane tests), and so does the mirror bounce of the tile's
+                                pixels that lie on one pure-specular plane (the reference scenes' mirror floors); 0: every
+                                ray walks on its own.  1M-triangle soup at 4K: 43.0 against 44.1 ms.  Pixels never depend
+                                on it */
     RT_OPTION_GPU_BUILD_MIN = 11, /* scenes whose two derived trees (re-treed leaves, tight tree) have at least this many
                                 items together (default 20000) get them built on the GPU: binned SAH, large nodes level by
                                 level, subtrees of <= 64 items by one wave each -- node arrays bit-identical to the host

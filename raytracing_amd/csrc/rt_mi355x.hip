@@ -494,6 +494,9 @@ int rt_set_option(rt_ctx* ctx, int option, int value) {
             if (value < 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "first sorted iteration must be >= 0 (0: no binning)");
             ctx->wf_bin_from = value;
             return RT_OK;
+        case RT_OPTION_PACKET_WALKS:
+            ctx->wf_packet = value != 0;
+            return RT_OK;
         case RT_OPTION_GPU_BUILD_MIN:
             if (value < -1) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "GPU build threshold must be >= -1");
             ctx->gpu_build_min = value;

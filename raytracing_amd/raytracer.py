@@ -96,7 +96,7 @@ class RayTracer:
             raise RtError(rc, self._lib.rt_last_error(self._ctx).decode())
 
     OPTION_USE_LDS, OPTION_SUPERTILE, OPTION_TRAVERSAL, OPTION_TIGHT_TREE, OPTION_WAVEFRONT_MIN_NODES = 1, 2, 3, 4, 5
-    OPTION_TIGHT_MIN_NODES, OPTION_COOP_SHADOWS, OPTION_GPU_FLATTEN_MIN, OPTION_FRAME_FEEDBACK, OPTION_BIN_PATHS, OPTION_GPU_BUILD_MIN = 6, 7, 8, 9, 10, 11
+    OPTION_TIGHT_MIN_NODES, OPTION_COOP_SHADOWS, OPTION_GPU_FLATTEN_MIN, OPTION_FRAME_FEEDBACK, OPTION_BIN_PATHS, OPTION_GPU_BUILD_MIN, OPTION_PACKET_WALKS = 6, 7, 8, 9, 10, 11, 12
     TRAVERSAL_AUTO, TRAVERSAL_WAVE, TRAVERSAL_BVH, TRAVERSAL_WAVEFRONT = 0, 1, 2, 3
 
     def set_option(self, option, value):

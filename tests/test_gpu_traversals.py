@@ -581,3 +581,30 @@ def test_binned_path_lists_change_no_pixel(name, params, depth, rt_mode, scene_o
             assert np.array_equal(out["rgb"].view(np.uint32), base["rgb"].view(np.uint32)), (name, first)
     finally:
         rt.set_option(rt.OPTION_BIN_PATHS, 0)
+
+
+@pytest.mark.parametrize("name,params,depth", [("TestScene1", None, 10), ("TeapotTable", None, 8), ("Soup", [20000, 200, 8], 4)])
+def test_packet_walks_change_no_pixel(name, params, depth, rt_mode, scene_of):
+    """RT_OPTION_PACKET_WALKS: the primary rays of a tile, and the mirror bounce of its pixels on one pure-specular plane
+    (the scenes' mirror floors), walk the tight tree as one packet.  Every plane must equal the per-ray walks' bit for bit
+    -- on a frame with ragged tiles, from a camera low over the floor (most tiles bounce), from one inside the scene --
+    and match the oracle."""
+    from raytracing_amd import host
+    rt = rt_mode
+    sc = scene_of(name, params)
+    _set_mode(rt, 4)
+    cams = [sc.camera_for(333, 190),
+            host.camera_pack([3.0, 0.4, -9.0], [-0.2, 0.05, 1.0], [1, 0, 0.2], 1.0, 1.6, 0.9, 161, 93),
+            host.camera_pack([0.5, 2.0, 0.5], [0.3, -0.4, 1.0], [1, 0, -0.3], 1.0, 1.6, 0.9, 128, 72)]
+    try:
+        for cam in cams:
+            rt.set_option(rt.OPTION_PACKET_WALKS, 0)
+            base = _render(rt, sc, cam, depth)
+            rt.set_option(rt.OPTION_PACKET_WALKS, 1)
+            out = _render(rt, sc, cam, depth)
+            for plane in ("primary_id", "final_id"):
+                assert np.array_equal(out[plane], base[plane]), (name, plane)
+            assert np.array_equal(out["rgb"].view(np.uint32), base["rgb"].view(np.uint32)), name
+        assert_frame_matches(out, oracle_render(sc, cams[-1], depth, threads=16), name + " packets")
+    finally:
+        rt.set_option(rt.OPTION_PACKET_WALKS, 1)
